@@ -1,0 +1,350 @@
+// dasp_kernels.hip — DepthAdaptiveSuperpixel on gfx950 (K5-K8).
+// Reference: SuperpixelSegmentation/DepthAdaptiveSuperpixel.cu:3-588.
+//
+// Re-architecture vs the reference:
+//   K7 calculateLD launches one 16-thread block per PIXEL in the reference (2.07 M blocks at 1080p);
+//      here one thread owns one pixel and walks its 16 candidate clusters in registers, with the
+//      cluster table (mean + centre, 32 B per cluster) staged in LDS.  The 16-way tree argmin and
+//      its tie-break order are kept exactly.
+//   K8 analyzeClusters keeps the reference's summation order (per-thread serial, then a 256-way
+//      tree) so the float sums agree bit for bit with the CPU restatement; the last six tree levels
+//      run as wavefront shuffles.
+//   All grids are ceil-div and bounds-guarded (D4); out-of-buffer taps of K6 read colour 0 (D1).
+#include "kde_internal.h"
+
+namespace kde {
+namespace {
+
+// ---- K5 init_LD (.cu:3-14) ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void init_ld_kernel(DaspGeom g, kde_label_distance* __restrict__ ld)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= g.width || y >= g.height) return;
+    kde_label_distance v;
+    v.l = (y / g.wy) * g.cols + (x / g.wx);
+    v.d = 999999.9f;
+    ld[(size_t)y * g.width + x] = v;
+}
+
+// ---- K6 sampleInitialClusters<16> (.cu:16-165) ---------------------------------------------------
+// one 64-lane wavefront = 4 clusters x 16 candidates
+__global__ __launch_bounds__(64) void sample_clusters_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
+                                                            const kde_float3* __restrict__ pts,
+                                                            kde_superpixel* __restrict__ mean,
+                                                            kde_float3* __restrict__ centers)
+{
+    const int lane = threadIdx.x;
+    const int sub = lane >> 4, tid = lane & 15;
+    const int cluster = blockIdx.x * 4 + sub;
+    const int nclusters = g.rows * g.cols;
+    const bool active = cluster < nclusters;
+    const int bx = active ? cluster % g.cols : 0, by = active ? cluster / g.cols : 0;
+    const int tx = tid & 3, ty = tid >> 2;
+    const int around_x = bx * g.wx + g.wx / 2 + tx - 2;
+    const int around_y = by * g.wy + g.wy / 2 + ty - 2;
+    const long npix = (long)g.width * g.height;
+    const uint8_t* ca = bgr + ((size_t)around_y * g.width + around_x) * 3;
+    const float a0 = (float)ca[0], a1 = (float)ca[1], a2 = (float)ca[2];
+    float sumG = 0.0f;
+    int count = 0;
+    for (int yy = -5; yy <= 5; yy++) {
+        for (int xx = -5; xx <= 5; xx++) {
+            const long idx = (long)yy * g.width + xx;   // absolute index, .cu:52-54
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+            if (idx >= 0 && idx < npix) {
+                t0 = (float)bgr[idx * 3];
+                t1 = (float)bgr[idx * 3 + 1];
+                t2 = (float)bgr[idx * 3 + 2];
+            }
+            const float d0 = a0 - t0, d1 = a1 - t1, d2 = a2 - t2;
+            const float gr = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+            count += gr > 0.0f ? 1 : 0;
+            sumG += gr;
+        }
+    }
+    float gradient = sumG / (float)count;
+    int ax = around_x, ay = around_y;
+    // 16-element tree argmin, strict '>' (.cu:106-149); lanes >= step of a sub-group carry garbage
+    // that element 0 never reads, exactly like the reference's lock-step warp
+#pragma unroll
+    for (int step = 8; step >= 1; step >>= 1) {
+        const float og = __shfl_down(gradient, step, 16);
+        const int ox = __shfl_down(ax, step, 16);
+        const int oy = __shfl_down(ay, step, 16);
+        if (tid < step && gradient > og) {
+            gradient = og;
+            ax = ox;
+            ay = oy;
+        }
+    }
+    if (active && tid == 0) {
+        const int id = by * (g.width / g.wx) + bx;
+        const uint8_t* cs = bgr + ((size_t)ay * g.width + ax) * 3;
+        kde_superpixel m = mean[id];
+        m.x = ax;
+        m.y = ay;
+        m.r = cs[0];
+        m.g = cs[1];
+        m.b = (uint8_t)(cs[0] + 2);   // sic, .cu:159
+        mean[id] = m;
+        centers[id] = pts[(size_t)ay * g.width + ax];
+    }
+}
+
+// ---- K7 calculateLD<16> (.cu:167-313) -------------------------------------------------------------
+struct ClusterRec {   // LDS copy of one cluster: 32 B
+    float r, g, b;
+    int x, y;
+    float cz;
+    int pad0, pad1;
+};
+
+constexpr int kMaxLdsClusters = 2048;   // 64 KiB of LDS
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
+                                                     const kde_float3* __restrict__ pts,
+                                                     kde_label_distance* __restrict__ ld,
+                                                     const kde_superpixel* __restrict__ mean,
+                                                     const kde_float3* __restrict__ centers,
+                                                     int32_t* __restrict__ labels, float kc, float ks, float kd,
+                                                     float win2, int depth_on)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ClusterRec* recs = reinterpret_cast<ClusterRec*>(smem);
+    const int nclusters = g.rows * g.cols;
+    if (USE_LDS) {
+        for (int i = threadIdx.x; i < nclusters; i += 256) {
+            const kde_superpixel m = mean[i];
+            ClusterRec r;
+            r.r = (float)m.r;
+            r.g = (float)m.g;
+            r.b = (float)m.b;
+            r.x = m.x;
+            r.y = m.y;
+            r.cz = centers[i].z;
+            r.pad0 = r.pad1 = 0;
+            recs[i] = r;
+        }
+        __syncthreads();
+    }
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= g.width || y >= g.height) return;
+    const size_t p = (size_t)y * g.width + x;
+    const kde_label_distance cur = ld[p];
+    const int ccx = cur.l % g.cols, ccy = cur.l / g.cols;
+    const float c0 = (float)bgr[p * 3], c1 = (float)bgr[p * 3 + 1], c2 = (float)bgr[p * 3 + 2];
+    const float z = pts[p].z;
+
+    float dist[16];
+    int lab[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int rx = ccx - 2 + (t & 3), ry = ccy - 2 + (t >> 2);
+        if (rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows) {
+            const int id = ry * g.cols + rx;
+            float mr, mg, mb, cz;
+            int mx, my;
+            if (USE_LDS) {
+                const ClusterRec r = recs[id];
+                mr = r.r; mg = r.g; mb = r.b; mx = r.x; my = r.y; cz = r.cz;
+            } else {
+                const kde_superpixel m = mean[id];
+                mr = (float)m.r; mg = (float)m.g; mb = (float)m.b; mx = m.x; my = m.y;
+                cz = centers[id].z;
+            }
+            const float e0 = c0 - mr, e1 = c1 - mg, e2 = c2 - mb;
+            const float color_distance = e0 * e0 + e1 * e1 + e2 * e2;
+            const float px = (float)(x - mx), py = (float)(y - my);
+            const float spatial_distance = sqrtf(px * px + py * py) * win2;
+            float depth_distance = 0.0f;
+            if (z > 50.0f && cz > 50.0f) depth_distance = fabsf(z - cz);
+            dist[t] = color_distance * kc + spatial_distance * ks + depth_distance * kd;   // .cu:218
+            lab[t] = id;
+        } else {
+            dist[t] = cur.d;   // .cu:221-224
+            lab[t] = cur.l;
+        }
+    }
+#pragma unroll
+    for (int step = 8; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int t = 0; t < step; t++) {
+            if (dist[t] > dist[t + step]) {
+                lab[t] = lab[t + step];
+                dist[t] = dist[t + step];
+            }
+        }
+    }
+    kde_label_distance o;
+    o.l = lab[0];
+    o.d = dist[0];
+    if (z < 50.0f && depth_on) {   // .cu:308-312
+        o.l = -1;
+        o.d = 0.0f;
+    }
+    ld[p] = o;
+    labels[p] = o.l;
+}
+
+// ---- K8 analyzeClusters<256> (.cu:315-568) ---------------------------------------------------------
+__device__ __forceinline__ int f2i_rz(float v) { return (int)v; }   // v_cvt_i32_f32: RZ, saturating, NaN -> 0
+
+__global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
+                                                              const kde_float3* __restrict__ pts,
+                                                              const kde_label_distance* __restrict__ ld,
+                                                              kde_superpixel* __restrict__ mean,
+                                                              kde_float3* __restrict__ centers,
+                                                              const float* __restrict__ intr)
+{
+    __shared__ int si[7][256];     // r g b x y size npoints
+    __shared__ float sf[3][256];   // X Y Z
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int cluster_id = blockIdx.y * g.cols + blockIdx.x;
+    const int rpx = g.wx * 2 / 16 + 1, rpy = g.wy * 2 / 16 + 1;
+    const kde_superpixel m0 = mean[cluster_id];
+
+    int r_ = 0, g_ = 0, b_ = 0, x_ = 0, y_ = 0, s_ = 0, n_ = 0;
+    float xf = 0.0f, yf = 0.0f, zf = 0.0f;
+    for (int yy = 0; yy < rpy; yy++) {
+        for (int xx = 0; xx < rpx; xx++) {
+            const int arx = m0.x + (tx - 8) * rpx + xx;
+            const int ary = m0.y + (ty - 8) * rpy + yy;
+            if (arx >= 0 && arx < g.width && ary >= 0 && ary < g.height) {
+                const size_t q = (size_t)ary * g.width + arx;
+                if (ld[q].l == cluster_id) {
+                    r_ += (int)bgr[q * 3];
+                    g_ += (int)bgr[q * 3 + 1];
+                    b_ += (int)bgr[q * 3 + 2];
+                    x_ += arx;
+                    y_ += ary;
+                    s_ += 1;
+                    const kde_float3 pt = pts[q];
+                    xf += pt.x;
+                    yf += pt.y;
+                    zf += pt.z;
+                    n_ += pt.z > 50.0f ? 1 : 0;
+                }
+            }
+        }
+    }
+    si[0][tid] = r_; si[1][tid] = g_; si[2][tid] = b_; si[3][tid] = x_; si[4][tid] = y_;
+    si[5][tid] = s_; si[6][tid] = n_;
+    sf[0][tid] = xf; sf[1][tid] = yf; sf[2][tid] = zf;
+    __syncthreads();
+    // tree levels +128, +64 through LDS (.cu:425-454)
+    if (tid < 128) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) si[k][tid] += si[k][tid + 128];
+#pragma unroll
+        for (int k = 0; k < 3; k++) sf[k][tid] += sf[k][tid + 128];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        int iv[7];
+        float fv[3];
+#pragma unroll
+        for (int k = 0; k < 7; k++) iv[k] = si[k][tid] + si[k][tid + 64];
+#pragma unroll
+        for (int k = 0; k < 3; k++) fv[k] = sf[k][tid] + sf[k][tid + 64];
+        // levels +32 ... +1 inside the wavefront (.cu:455-528); lane 0 sees the clean tree
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) iv[k] += __shfl_down(iv[k], step, 64);
+#pragma unroll
+            for (int k = 0; k < 3; k++) fv[k] += __shfl_down(fv[k], step, 64);
+        }
+        if (tid == 0 && iv[5] != 0) {   // .cu:530-566
+            const int size = iv[5], np = iv[6];
+            int r = iv[0] / size > 255 ? 255 : iv[0] / size;
+            int gg = iv[1] / size > 255 ? 255 : iv[1] / size;
+            int b = iv[2] / size > 255 ? 255 : iv[2] / size;
+            r = r < 0 ? 0 : r;
+            gg = gg < 0 ? 0 : gg;
+            b = b < 0 ? 0 : b;
+            int pix_x, pix_y;
+            if (np != 0) {
+                kde_float3 c;
+                c.x = fv[0] / (float)np;
+                c.y = fv[1] / (float)np;
+                c.z = fv[2] / (float)np;
+                centers[cluster_id] = c;
+                const float nx = c.x / c.z, ny = c.y / c.z;
+                pix_x = f2i_rz(nx * intr[0] + intr[2]);
+                pix_y = f2i_rz(intr[5] - ny * intr[4]);
+                if (pix_x < 0 || pix_x >= g.width || pix_y < 0 || pix_y <= g.height) {   // sic, .cu:549
+                    pix_x = iv[3] / size;
+                    pix_y = iv[4] / size;
+                }
+            } else {
+                pix_x = iv[3] / size;
+                pix_y = iv[4] / size;
+            }
+            kde_superpixel m;
+            m.r = (uint8_t)r;
+            m.g = (uint8_t)gg;
+            m.b = (uint8_t)b;
+            m.pad_ = 0;
+            m.x = pix_x;
+            m.y = pix_y;
+            m.size = size;
+            mean[cluster_id] = m;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_dasp_init_ld(const DaspGeom& g, kde_label_distance* ld, hipStream_t s)
+{
+    hipLaunchKernelGGL(init_ld_kernel, dim3(ceil_div(g.width, 64), ceil_div(g.height, 4)), dim3(256), 0, s, g, ld);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_dasp_sample(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
+                       kde_float3* centers, hipStream_t s)
+{
+    hipLaunchKernelGGL(sample_clusters_kernel, dim3(ceil_div(g.rows * g.cols, 4)), dim3(64), 0, s, g, bgr, pts, mean,
+                       centers);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_dasp_calc_ld(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld,
+                        const kde_superpixel* mean, const kde_float3* centers, int32_t* labels, float color_sigma,
+                        float spatial_sigma, float depth_sigma, hipStream_t s)
+{
+    // host-side scalars formed exactly as .cu:209-218 does per thread
+    const float half = (float)(g.wx + g.wy) / 2.0f;
+    const float win2 = half * half;
+    const float sum_sigma = spatial_sigma + color_sigma + depth_sigma;
+    const float rc = color_sigma / sum_sigma, rs = spatial_sigma / sum_sigma, rd = depth_sigma / sum_sigma;
+    const float kc = rc * rc, ks = rs * rs, kd = rd * rd;
+    const int nclusters = g.rows * g.cols;
+    dim3 grid(ceil_div(g.width, 64), ceil_div(g.height, 4));
+    if (nclusters <= kMaxLdsClusters) {
+        hipLaunchKernelGGL(calc_ld_kernel<true>, grid, dim3(256), (size_t)nclusters * sizeof(ClusterRec), s, g, bgr, pts,
+                           ld, mean, centers, labels, kc, ks, kd, win2, depth_sigma != 0.0f ? 1 : 0);
+    } else {
+        hipLaunchKernelGGL(calc_ld_kernel<false>, grid, dim3(256), 0, s, g, bgr, pts, ld, mean, centers, labels, kc, ks,
+                           kd, win2, depth_sigma != 0.0f ? 1 : 0);
+    }
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const kde_label_distance* ld,
+                        kde_superpixel* mean, kde_float3* centers, const float* intr_dev, hipStream_t s)
+{
+    hipLaunchKernelGGL(analyze_clusters_kernel, dim3(g.cols, g.rows), dim3(256), 0, s, g, bgr, pts, ld, mean, centers,
+                       intr_dev);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+}  // namespace kde

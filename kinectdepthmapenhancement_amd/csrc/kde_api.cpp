@@ -1,0 +1,942 @@
+// kde_api.cpp — the extern "C" surface of libkde_hip.so (include/kde_hip.h): handle objects that
+// mirror the reference classes' members and ownership, argument validation, error codes.
+#include "kde_internal.h"
+
+#include <cfloat>
+#include <climits>
+
+namespace kde {
+
+// ---- errors ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "no error";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ---- host math shared by several objects ------------------------------------------------------------
+float exp_zero_threshold()
+{
+    // exp(-x) rounds to 0 in binary32 iff exp(-x) < 2^-150 iff x > 150 ln 2
+    const double t = 150.0 * 0.693147180559945309417232121458;
+    float f = (float)t;
+    while ((double)f <= t) f = std::nextafterf(f, INFINITY);
+    while ((double)std::nextafterf(f, 0.0f) > t) f = std::nextafterf(f, 0.0f);
+    return f;
+}
+
+void spatial_table(int window, float sigma, float* table)
+{
+    // JointBilateralFilter.cpp:31-40 (powf(x, 2.0f) written x*x)
+    for (int i = 0; i < window; i++)
+        for (int j = 0; j < window; j++) {
+            const float fx = (float)(j - window / 2), fy = (float)(i - window / 2);
+            const float dis_x = fx * fx, dis_y = fy * fy;
+            table[i * window + j] = expf(-(dis_x + dis_y) / (2.0f * (sigma * sigma)));
+        }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// smallest non-negative float q with q / den >= thr (float division); +inf if none
+static float smallest_q_reaching(float den, float thr)
+{
+    if (!(den > 0.0f)) return 0.0f;
+    uint32_t lo = 0, hi = 0x7f800000u;   // bit patterns of +0 .. +inf are ordered like the values
+    auto val = [](uint32_t b) { float f; memcpy(&f, &b, 4); return f; };
+    if (!(val(hi) / den >= thr)) return INFINITY;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (val(mid) / den >= thr) hi = mid;
+        else lo = mid + 1;
+    }
+    return val(lo);
+}
+
+}  // namespace kde
+
+using namespace kde;
+
+// =====================================================================================================
+// library
+// =====================================================================================================
+extern "C" int kde_abi_version(void) { return KDE_ABI_VERSION; }
+extern "C" const char* kde_last_error_string(void) { return g_err; }
+
+extern "C" int kde_device_count(int* count)
+{
+    KDE_REQUIRE(count, "kde_device_count: null argument");
+    KDE_HIP_TRY(hipGetDeviceCount(count));
+    return KDE_OK;
+}
+
+extern "C" int kde_set_device(int device)
+{
+    KDE_HIP_TRY(hipSetDevice(device));
+    return KDE_OK;
+}
+
+extern "C" int kde_device_info(char* arch_buf, size_t arch_cap, int* cu_count)
+{
+    int dev = 0;
+    KDE_HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    KDE_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (arch_buf && arch_cap) snprintf(arch_buf, arch_cap, "%s", prop.gcnArchName);
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    return KDE_OK;
+}
+
+// =====================================================================================================
+// JointBilateralFilter
+// =====================================================================================================
+struct kde_jbf {
+    int width = 0, height = 0, max_batch = 1;
+    kde_jbf_params p{};
+    std::vector<float> table;       // SpatialFilter_Host
+    DevBuf<float> s_eff;            // SpatialFilter_Device (zeros replaced by 1: "skip the factor")
+    DevBuf<float> filtered;         // Filtered_Device
+    DevBuf<uint8_t> smooth;         // smooth_Device
+    DevBuf<float> pre_lut;          // K0 weight table
+    PinnedBuf<float> filtered_host; // Filtered_Host
+    int pre_radius = 0;
+    float color_den = 0, depth_den = 0;
+    int cd_skip = INT_MAX;
+    float d2_skip = INFINITY;
+    int variant = -1;
+    int n_last = 0;
+    float* last_out = nullptr;
+};
+
+extern "C" int kde_jbf_default_params(kde_jbf_params* p)
+{
+    KDE_REQUIRE(p, "kde_jbf_default_params: null argument");
+    p->window_size = 5;              // JointBilateralFilter.cpp:3
+    p->spatial_sigma = 70.0f;        // :4
+    p->color_sigma = 50.0f;          // :5
+    p->depth_sigma = 20.0f;          // :6
+    p->presmooth = 1;                // JointBilateralFilter.cu:285
+    p->presmooth_kernel_size = 5;
+    p->presmooth_sigma_color = 30.0f;
+    p->presmooth_sigma_spatial = 30.0f;
+    return KDE_OK;
+}
+
+extern "C" int kde_jbf_create(kde_jbf** out, int width, int height, int max_batch, const kde_jbf_params* params)
+{
+    KDE_REQUIRE(out, "kde_jbf_create: null out");
+    *out = nullptr;
+    KDE_REQUIRE(width >= 1 && height >= 1 && (long long)width * height <= (1ll << 30), "kde_jbf_create: bad size %dx%d", width, height);
+    KDE_REQUIRE(max_batch >= 1 && max_batch <= 65535, "kde_jbf_create: max_batch must be in 1..65535");
+    kde_jbf_params p;
+    kde_jbf_default_params(&p);
+    if (params) p = *params;
+    KDE_REQUIRE(p.window_size >= 1 && p.window_size <= 31 && (p.window_size & 1), "kde_jbf_create: window_size must be odd in 1..31");
+    KDE_REQUIRE(p.spatial_sigma == p.spatial_sigma && p.color_sigma >= 0.0f && p.depth_sigma >= 0.0f && p.spatial_sigma != 0.0f,
+                "kde_jbf_create: sigmas must be >= 0 (spatial != 0)");
+    kde_jbf* h = new (std::nothrow) kde_jbf;
+    if (!h) return fail(KDE_ERR_NOMEM, "kde_jbf_create: out of host memory");
+    h->width = width;
+    h->height = height;
+    h->max_batch = max_batch;
+    h->p = p;
+    const int w = p.window_size;
+    h->table.resize((size_t)w * w);
+    spatial_table(w, p.spatial_sigma, h->table.data());
+    std::vector<float> eff(h->table);
+    for (float& v : eff)
+        if (v == 0.0f) v = 1.0f;   // "if(spatial != 0) filter *= spatial" (JointBilateralFilter.cu:30-31)
+    const size_t px = (size_t)width * height;
+    int rc = h->s_eff.alloc(eff.size());
+    if (rc == KDE_OK) rc = h->filtered.alloc(px * max_batch);
+    if (rc == KDE_OK) rc = h->smooth.alloc(px * 3 * max_batch);
+    if (rc == KDE_OK && hipMemcpy(h->s_eff.p, eff.data(), eff.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(KDE_ERR_HIP, "kde_jbf_create: table upload failed");
+    // thresholds of the "factor == 0 -> skipped" rule (JointBilateralFilter.cu:32-33, 65-68)
+    const float xz = exp_zero_threshold();
+    h->color_den = 2 * (p.color_sigma * p.color_sigma);
+    h->depth_den = 2.0f * (p.depth_sigma * p.depth_sigma);
+    h->cd_skip = INT_MAX;
+    if (p.color_sigma != 0.0f) {
+        int lo = 0, hi = 195076;   // 3*255^2 + 1
+        while (lo < hi) {
+            const int mid = (lo + hi) / 2;
+            if ((float)mid / h->color_den >= xz) hi = mid;
+            else lo = mid + 1;
+        }
+        h->cd_skip = lo;   // 195076 = never reached
+    }
+    h->d2_skip = p.depth_sigma != 0.0f ? smallest_q_reaching(h->depth_den, xz) : INFINITY;
+    // K0 table: weight(space2, n1) = expf(space2*ss + n1^2*sc), the expression of OpenCV's kernel
+    if (rc == KDE_OK && p.presmooth) {
+        float sc_ = p.presmooth_sigma_color, ss_ = p.presmooth_sigma_spatial;
+        sc_ = (sc_ <= 0) ? 1 : sc_;
+        ss_ = (ss_ <= 0) ? 1 : ss_;
+        int radius = (p.presmooth_kernel_size <= 0) ? (int)rint((double)ss_ * 1.5) : p.presmooth_kernel_size / 2;
+        radius = radius > 1 ? radius : 1;
+        if (radius > 4) {
+            delete h;
+            return fail(KDE_ERR_UNSUPPORTED, "kde_jbf_create: pre-smoothing radius %d > 4 is not built", radius);
+        }
+        h->pre_radius = radius;
+        const float ss = -0.5f / (ss_ * ss_), sc = -0.5f / (sc_ * sc_);
+        std::vector<float> lut((size_t)(radius * radius + 1) * 766);
+        for (int s2 = 0; s2 <= radius * radius; s2++)
+            for (int n1 = 0; n1 < 766; n1++) {
+                const float fn = (float)n1;
+                lut[(size_t)s2 * 766 + n1] = expf((float)s2 * ss + (fn * fn) * sc);
+            }
+        rc = h->pre_lut.alloc(lut.size());
+        if (rc == KDE_OK && hipMemcpy(h->pre_lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(KDE_ERR_HIP, "kde_jbf_create: lut upload failed");
+    }
+    if (rc != KDE_OK) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return KDE_OK;
+}
+
+extern "C" int kde_jbf_destroy(kde_jbf* h)
+{
+    delete h;
+    return KDE_OK;
+}
+
+static int jbf_filter(kde_jbf* h, int n, const float* depth, const uint8_t* guide, float* out, hipStream_t s)
+{
+    JbfLaunch a;
+    a.width = h->width;
+    a.height = h->height;
+    a.n = n;
+    a.window = h->p.window_size;
+    a.depth = depth;
+    a.guide = guide;
+    a.out = out;
+    a.s_eff = h->s_eff.p;
+    a.color_sigma = h->p.color_sigma;
+    a.depth_sigma = h->p.depth_sigma;
+    a.color_den = h->color_den;
+    a.depth_den = h->depth_den;
+    a.cd_skip = h->cd_skip;
+    a.d2_skip = h->d2_skip;
+    a.variant = h->variant;
+    return launch_jbf(a, s);
+}
+
+static int jbf_presmooth(kde_jbf* h, int n, const uint8_t* bgr, uint8_t* dst, hipStream_t s)
+{
+    PresmoothLaunch a;
+    a.width = h->width;
+    a.height = h->height;
+    a.n = n;
+    a.radius = h->pre_radius;
+    a.src = bgr;
+    a.dst = dst;
+    a.lut = h->pre_lut.p;
+    return launch_presmooth(a, s);
+}
+
+extern "C" int kde_jbf_process_batch(kde_jbf* h, int n, const float* depth_dev, const uint8_t* bgr_dev,
+                                     float* filtered_dev, void* stream)
+{
+    KDE_REQUIRE(h && depth_dev && bgr_dev, "kde_jbf_process_batch: null argument");
+    KDE_REQUIRE(n >= 1 && n <= h->max_batch, "kde_jbf_process_batch: n=%d outside 1..max_batch=%d", n, h->max_batch);
+    hipStream_t s = as_stream(stream);
+    float* out = filtered_dev ? filtered_dev : h->filtered.p;
+    const uint8_t* guide = bgr_dev;
+    if (h->p.presmooth) {
+        KDE_TRY(jbf_presmooth(h, n, bgr_dev, h->smooth.p, s));
+        guide = h->smooth.p;
+    }
+    KDE_TRY(jbf_filter(h, n, depth_dev, guide, out, s));
+    h->n_last = n;
+    h->last_out = out;
+    return KDE_OK;
+}
+
+extern "C" int kde_jbf_process(kde_jbf* h, const float* depth_dev, const uint8_t* bgr_dev, size_t bgr_step, void* stream)
+{
+    KDE_REQUIRE(h, "kde_jbf_process: null handle");
+    KDE_REQUIRE(bgr_step == (size_t)h->width * 3, "kde_jbf_process: colour image must be continuous (step %zu != 3*width)", bgr_step);
+    return kde_jbf_process_batch(h, 1, depth_dev, bgr_dev, nullptr, stream);
+}
+
+extern "C" int kde_jbf_presmooth_batch(kde_jbf* h, int n, const uint8_t* bgr_dev, uint8_t* smooth_dev, void* stream)
+{
+    KDE_REQUIRE(h && bgr_dev, "kde_jbf_presmooth_batch: null argument");
+    KDE_REQUIRE(h->p.presmooth, "kde_jbf_presmooth_batch: handle was created with presmooth = 0");
+    KDE_REQUIRE(n >= 1 && (smooth_dev || n <= h->max_batch), "kde_jbf_presmooth_batch: bad n");
+    return jbf_presmooth(h, n, bgr_dev, smooth_dev ? smooth_dev : h->smooth.p, as_stream(stream));
+}
+
+extern "C" int kde_jbf_filter_batch(kde_jbf* h, int n, const float* depth_dev, const uint8_t* guide_bgr_dev,
+                                    float* filtered_dev, void* stream)
+{
+    KDE_REQUIRE(h && depth_dev && guide_bgr_dev, "kde_jbf_filter_batch: null argument");
+    KDE_REQUIRE(n >= 1 && n <= 65535 && (filtered_dev || n <= h->max_batch), "kde_jbf_filter_batch: bad n");
+    float* out = filtered_dev ? filtered_dev : h->filtered.p;
+    KDE_TRY(jbf_filter(h, n, depth_dev, guide_bgr_dev, out, as_stream(stream)));
+    h->n_last = n;
+    h->last_out = out;
+    return KDE_OK;
+}
+
+extern "C" int kde_jbf_filtered_device(kde_jbf* h, float** out)
+{
+    KDE_REQUIRE(h && out, "kde_jbf_filtered_device: null argument");
+    *out = h->filtered.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_jbf_filtered_host(kde_jbf* h, void* stream, const float** out)
+{
+    KDE_REQUIRE(h && out, "kde_jbf_filtered_host: null argument");
+    const size_t count = (size_t)h->width * h->height * (h->n_last > 0 ? h->n_last : 1);
+    KDE_TRY(h->filtered_host.ensure((size_t)h->width * h->height * h->max_batch));
+    const float* src = h->last_out ? h->last_out : h->filtered.p;
+    KDE_HIP_TRY(hipMemcpyAsync(h->filtered_host.p, src, count * sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
+    KDE_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    *out = h->filtered_host.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_jbf_smooth_device(kde_jbf* h, uint8_t** out)
+{
+    KDE_REQUIRE(h && out, "kde_jbf_smooth_device: null argument");
+    *out = h->smooth.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_jbf_spatial_table(kde_jbf* h, float* table_host, int capacity)
+{
+    KDE_REQUIRE(h && table_host, "kde_jbf_spatial_table: null argument");
+    KDE_REQUIRE(capacity >= (int)h->table.size(), "kde_jbf_spatial_table: capacity %d < %zu", capacity, h->table.size());
+    memcpy(table_host, h->table.data(), h->table.size() * sizeof(float));
+    return KDE_OK;
+}
+
+extern "C" int kde_jbf_set_variant(kde_jbf* h, int variant)
+{
+    KDE_REQUIRE(h, "kde_jbf_set_variant: null handle");
+    KDE_REQUIRE(variant >= -1 && variant < jbf_variant_count(), "kde_jbf_set_variant: variant %d out of range", variant);
+    h->variant = variant;
+    return KDE_OK;
+}
+
+extern "C" int kde_jbf_variant_count(void) { return jbf_variant_count(); }
+extern "C" const char* kde_jbf_variant_name(int variant) { return jbf_variant_name(variant); }
+
+// =====================================================================================================
+// MarkovRandomField
+// =====================================================================================================
+struct kde_mrf {
+    int width, height, max_batch, window;
+    float color_sigma, smooth_sigma;
+    DevBuf<float> filtered;
+};
+
+extern "C" int kde_mrf_create(kde_mrf** out, int width, int height, int max_batch, int window, float color_sigma, float smooth_sigma)
+{
+    KDE_REQUIRE(out, "kde_mrf_create: null out");
+    *out = nullptr;
+    KDE_REQUIRE(width >= 1 && height >= 1 && max_batch >= 1 && max_batch <= 65535, "kde_mrf_create: bad size");
+    if (window <= 0) window = 5;                  // MarkovRandomField.cpp:3
+    if (color_sigma < 0.0f) color_sigma = 50.0f;  // :5
+    if (smooth_sigma < 0.0f) smooth_sigma = 150.0f;  // :6
+    KDE_REQUIRE(window <= 31 && (window & 1), "kde_mrf_create: window must be odd <= 31");
+    kde_mrf* h = new (std::nothrow) kde_mrf;
+    if (!h) return fail(KDE_ERR_NOMEM, "kde_mrf_create: out of host memory");
+    h->width = width; h->height = height; h->max_batch = max_batch; h->window = window;
+    h->color_sigma = color_sigma; h->smooth_sigma = smooth_sigma;
+    int rc = h->filtered.alloc((size_t)width * height * max_batch);
+    if (rc != KDE_OK) { delete h; return rc; }
+    *out = h;
+    return KDE_OK;
+}
+
+extern "C" int kde_mrf_destroy(kde_mrf* h) { delete h; return KDE_OK; }
+
+extern "C" int kde_mrf_process_batch(kde_mrf* h, int n, const float* depth_dev, const uint8_t* bgr_dev, float* filtered_dev, void* stream)
+{
+    KDE_REQUIRE(h && depth_dev && bgr_dev, "kde_mrf_process_batch: null argument");
+    KDE_REQUIRE(n >= 1 && n <= 65535 && (filtered_dev || n <= h->max_batch), "kde_mrf_process_batch: bad n");
+    MrfLaunch a{h->width, h->height, n, h->window, depth_dev, bgr_dev, filtered_dev ? filtered_dev : h->filtered.p,
+                h->color_sigma, h->smooth_sigma};
+    return launch_mrf(a, as_stream(stream));
+}
+
+extern "C" int kde_mrf_filtered_device(kde_mrf* h, float** out)
+{
+    KDE_REQUIRE(h && out, "kde_mrf_filtered_device: null argument");
+    *out = h->filtered.p;
+    return KDE_OK;
+}
+
+// =====================================================================================================
+// DimensionConvertor
+// =====================================================================================================
+struct kde_dimconv {
+    Camera cam{};
+    bool set = false;
+};
+
+extern "C" int kde_dimconv_create(kde_dimconv** out)
+{
+    KDE_REQUIRE(out, "kde_dimconv_create: null out");
+    *out = new (std::nothrow) kde_dimconv;
+    return *out ? KDE_OK : fail(KDE_ERR_NOMEM, "kde_dimconv_create: out of host memory");
+}
+
+extern "C" int kde_dimconv_destroy(kde_dimconv* h) { delete h; return KDE_OK; }
+
+extern "C" int kde_dimconv_set_camera(kde_dimconv* h, const double* K, int width, int height)
+{
+    KDE_REQUIRE(h && K, "kde_dimconv_set_camera: null argument");
+    KDE_REQUIRE(width >= 1 && height >= 1 && (long long)width * height <= (1ll << 30), "kde_dimconv_set_camera: bad size");
+    // DimensionConvertor.cpp:3-13
+    h->cam.fx = (float)K[0];
+    h->cam.fy = (float)K[4];
+    h->cam.cx = (int)K[2];
+    h->cam.cy = (int)K[5];
+    h->cam.width = width;
+    h->cam.height = height;
+    h->set = true;
+    return KDE_OK;
+}
+
+static int dimconv_check(kde_dimconv* h, int n, const void* in, const void* out, const char* who)
+{
+    KDE_REQUIRE(h && in && out, "%s: null argument", who);
+    KDE_REQUIRE(h->set, "%s: setCameraParameters was not called", who);
+    KDE_REQUIRE(n >= 1 && n <= 65535, "%s: bad frame count %d", who, n);
+    KDE_REQUIRE(aligned16(in) && aligned16(out), "%s: device pointers must be 16-byte aligned", who);
+    KDE_REQUIRE(n == 1 || ((size_t)h->cam.width * h->cam.height) % 4 == 0, "%s: batched call needs width*height %% 4 == 0", who);
+    return KDE_OK;
+}
+
+extern "C" int kde_dimconv_projective_to_real_depth(kde_dimconv* h, int n, const float* depth_dev, kde_float3* out_dev, void* stream)
+{
+    KDE_TRY(dimconv_check(h, n, depth_dev, out_dev, "kde_dimconv_projective_to_real_depth"));
+    return launch_p2r_depth(h->cam, n, depth_dev, out_dev, as_stream(stream));
+}
+
+extern "C" int kde_dimconv_projective_to_real_points(kde_dimconv* h, int n, const kde_float3* in_dev, kde_float3* out_dev, void* stream)
+{
+    KDE_TRY(dimconv_check(h, n, in_dev, out_dev, "kde_dimconv_projective_to_real_points"));
+    return launch_p2r_points(h->cam, n, in_dev, out_dev, as_stream(stream));
+}
+
+extern "C" int kde_dimconv_projective_to_real_interp(kde_dimconv* h, int n, const float* depth_dev, kde_float3* out_dev, void* stream)
+{
+    KDE_TRY(dimconv_check(h, n, depth_dev, out_dev, "kde_dimconv_projective_to_real_interp"));
+    return launch_p2r_interp(h->cam, n, depth_dev, out_dev, as_stream(stream));
+}
+
+extern "C" int kde_dimconv_real_to_projective(kde_dimconv* h, int n, const kde_float3* in_dev, kde_float3* out_dev, void* stream)
+{
+    KDE_TRY(dimconv_check(h, n, in_dev, out_dev, "kde_dimconv_real_to_projective"));
+    return launch_r2p(h->cam, n, in_dev, out_dev, as_stream(stream));
+}
+
+// =====================================================================================================
+// Buffer2D
+// =====================================================================================================
+struct kde_buffer2d {
+    int width, height;
+    DevBuf<kde_weighted_d> buf;   // devPtr
+};
+
+extern "C" int kde_buffer2d_create(kde_buffer2d** out, int width, int height)
+{
+    KDE_REQUIRE(out, "kde_buffer2d_create: null out");
+    *out = nullptr;
+    KDE_REQUIRE(width >= 1 && height >= 1 && (long long)width * height <= (1ll << 30), "kde_buffer2d_create: bad size");
+    kde_buffer2d* h = new (std::nothrow) kde_buffer2d;
+    if (!h) return fail(KDE_ERR_NOMEM, "kde_buffer2d_create: out of host memory");
+    h->width = width;
+    h->height = height;
+    int rc = h->buf.alloc((size_t)width * height);
+    if (rc == KDE_OK) rc = launch_buf_init(h->buf.p, h->buf.n, nullptr);   // initDeviceMemoryElements
+    if (rc == KDE_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(KDE_ERR_HIP, "kde_buffer2d_create: init failed");
+    if (rc != KDE_OK) { delete h; return rc; }
+    *out = h;
+    return KDE_OK;
+}
+
+extern "C" int kde_buffer2d_destroy(kde_buffer2d* h) { delete h; return KDE_OK; }
+
+extern "C" int kde_buffer2d_insert_depth(kde_buffer2d* h, const float* depth_dev, void* stream)
+{
+    KDE_REQUIRE(h && depth_dev, "kde_buffer2d_insert_depth: null argument");
+    KDE_REQUIRE(aligned16(depth_dev), "kde_buffer2d_insert_depth: device pointer must be 16-byte aligned");
+    return launch_buf_insert_depth(h->buf.p, depth_dev, h->buf.n, as_stream(stream));
+}
+
+extern "C" int kde_buffer2d_insert_float2(kde_buffer2d* h, const float* xy_dev, void* stream)
+{
+    KDE_REQUIRE(h && xy_dev, "kde_buffer2d_insert_float2: null argument");
+    KDE_REQUIRE((reinterpret_cast<uintptr_t>(xy_dev) & 7u) == 0, "kde_buffer2d_insert_float2: pointer must be 8-byte aligned");
+    return launch_buf_insert_float2(h->buf.p, xy_dev, h->width, h->height, as_stream(stream));
+}
+
+extern "C" int kde_buffer2d_insert_weighted(kde_buffer2d* h, const kde_weighted_d* data_dev, void* stream)
+{
+    KDE_REQUIRE(h && data_dev, "kde_buffer2d_insert_weighted: null argument");
+    KDE_HIP_TRY(hipMemcpyAsync(h->buf.p, data_dev, h->buf.n * sizeof(kde_weighted_d), hipMemcpyDeviceToDevice, as_stream(stream)));
+    return KDE_OK;
+}
+
+extern "C" int kde_buffer2d_get_depth_map(kde_buffer2d* h, float* out_dev, void* stream)
+{
+    KDE_REQUIRE(h && out_dev, "kde_buffer2d_get_depth_map: null argument");
+    KDE_REQUIRE(aligned16(out_dev), "kde_buffer2d_get_depth_map: device pointer must be 16-byte aligned");
+    return launch_buf_get(h->buf.p, out_dev, h->buf.n, 0, as_stream(stream));
+}
+
+extern "C" int kde_buffer2d_get_weight_map(kde_buffer2d* h, float* out_dev, void* stream)
+{
+    KDE_REQUIRE(h && out_dev, "kde_buffer2d_get_weight_map: null argument");
+    KDE_REQUIRE(aligned16(out_dev), "kde_buffer2d_get_weight_map: device pointer must be 16-byte aligned");
+    return launch_buf_get(h->buf.p, out_dev, h->buf.n, 1, as_stream(stream));
+}
+
+extern "C" int kde_buffer2d_update_sequence(kde_buffer2d* h, int n_frames, const float* depth_dev, void* stream)
+{
+    KDE_REQUIRE(h && depth_dev, "kde_buffer2d_update: null argument");
+    KDE_REQUIRE(n_frames >= 1, "kde_buffer2d_update: n_frames must be >= 1");
+    KDE_REQUIRE(aligned16(depth_dev) && (n_frames == 1 || h->buf.n % 2 == 0),
+                "kde_buffer2d_update: pointer must be 16-byte aligned (and width*height even for sequences)");
+    return launch_buf_update(h->buf.p, depth_dev, h->buf.n, n_frames, as_stream(stream));
+}
+
+extern "C" int kde_buffer2d_update(kde_buffer2d* h, const float* depth_dev, void* stream)
+{
+    return kde_buffer2d_update_sequence(h, 1, depth_dev, stream);
+}
+
+extern "C" int kde_buffer2d_raw_pointer(kde_buffer2d* h, kde_weighted_d** out)
+{
+    KDE_REQUIRE(h && out, "kde_buffer2d_raw_pointer: null argument");
+    *out = h->buf.p;
+    return KDE_OK;
+}
+
+// =====================================================================================================
+// DepthAdaptiveSuperpixel
+// =====================================================================================================
+struct kde_dasp {
+    int width, height;
+    bool set = false;
+    DaspGeom g{};
+    DevBuf<int32_t> labels;              // Labels_Device
+    DevBuf<kde_label_distance> ld;       // LD_Device
+    DevBuf<kde_superpixel> mean;         // meanData_Device
+    DevBuf<kde_float3> centers;          // superpixelCenters_Device
+    DevBuf<float> intr;                  // intrinsicDevice
+    PinnedBuf<int32_t> labels_host;      // Labels_Host
+};
+
+extern "C" int kde_dasp_create(kde_dasp** out, int width, int height)
+{
+    KDE_REQUIRE(out, "kde_dasp_create: null out");
+    *out = nullptr;
+    KDE_REQUIRE(width >= 1 && height >= 1 && (long long)width * height <= (1ll << 30), "kde_dasp_create: bad size");
+    kde_dasp* h = new (std::nothrow) kde_dasp;
+    if (!h) return fail(KDE_ERR_NOMEM, "kde_dasp_create: out of host memory");
+    h->width = width;
+    h->height = height;
+    const size_t px = (size_t)width * height;
+    int rc = h->labels.alloc(px);                 // SuperpixelSegmentation.cpp (ctor)
+    if (rc == KDE_OK) rc = h->ld.alloc(px);
+    if (rc == KDE_OK) rc = h->intr.alloc(9);      // DepthAdaptiveSuperpixel.cpp:6
+    if (rc != KDE_OK) { delete h; return rc; }
+    *out = h;
+    return KDE_OK;
+}
+
+extern "C" int kde_dasp_destroy(kde_dasp* h) { delete h; return KDE_OK; }
+
+static int dasp_geometry(int width, int height, int rows, int cols, DaspGeom* g)
+{
+    KDE_REQUIRE(rows >= 1 && cols >= 1, "SetParametor: rows and cols must be >= 1");
+    const int wx = width / cols, wy = height / rows;   // DepthAdaptiveSuperpixel.cpp:19-21
+    KDE_REQUIRE(wx >= 4 && wy >= 4, "SetParametor: window %dx%d < 4x4 (the 4x4 candidate grid would leave the image)", wx, wy);
+    KDE_REQUIRE(width / wx == cols, "SetParametor: width/(width/cols) != cols (cluster table would be indexed out of bounds)");
+    KDE_REQUIRE(height >= 6, "SetParametor: height must be >= 6");
+    g->width = width; g->height = height; g->rows = rows; g->cols = cols; g->wx = wx; g->wy = wy;
+    return KDE_OK;
+}
+
+extern "C" int kde_dasp_set_parameters(kde_dasp* h, int rows, int cols, const double* K)
+{
+    KDE_REQUIRE(h && K, "kde_dasp_set_parameters: null argument");
+    DaspGeom g;
+    KDE_TRY(dasp_geometry(h->width, h->height, rows, cols, &g));
+    const size_t k = (size_t)rows * cols;
+    KDE_TRY(h->mean.alloc(k));       // initMemory, DepthAdaptiveSuperpixel.cpp:40-50
+    KDE_TRY(h->centers.alloc(k));
+    KDE_HIP_TRY(hipMemset(h->mean.p, 0, k * sizeof(kde_superpixel)));
+    KDE_HIP_TRY(hipMemset(h->centers.p, 0, k * sizeof(kde_float3)));
+    float intr[9];
+    for (int i = 0; i < 9; i++) intr[i] = (float)K[i];   // DepthAdaptiveSuperpixel.cpp:33-37
+    KDE_HIP_TRY(hipMemcpy(h->intr.p, intr, sizeof(intr), hipMemcpyHostToDevice));
+    h->g = g;
+    h->set = true;
+    return KDE_OK;
+}
+
+extern "C" int kde_dasp_segmentation(kde_dasp* h, const uint8_t* bgr_dev, const kde_float3* points_dev,
+                                     float color_sigma, float spatial_sigma, float depth_sigma, int iteration, void* stream)
+{
+    KDE_REQUIRE(h && bgr_dev && points_dev, "kde_dasp_segmentation: null argument");
+    KDE_REQUIRE(h->set, "kde_dasp_segmentation: SetParametor was not called");
+    KDE_REQUIRE(iteration >= 0, "kde_dasp_segmentation: negative iteration count");
+    hipStream_t s = as_stream(stream);
+    // DepthAdaptiveSuperpixel.cu:570-586
+    KDE_TRY(launch_dasp_init_ld(h->g, h->ld.p, s));
+    KDE_TRY(launch_dasp_sample(h->g, bgr_dev, points_dev, h->mean.p, h->centers.p, s));
+    for (int i = 0; i < iteration; i++) {
+        KDE_TRY(launch_dasp_calc_ld(h->g, bgr_dev, points_dev, h->ld.p, h->mean.p, h->centers.p, h->labels.p,
+                                    color_sigma, spatial_sigma, depth_sigma, s));
+        KDE_TRY(launch_dasp_analyze(h->g, bgr_dev, points_dev, h->ld.p, h->mean.p, h->centers.p, h->intr.p, s));
+    }
+    return KDE_OK;
+}
+
+extern "C" int kde_dasp_labels_device(kde_dasp* h, int32_t** out)
+{
+    KDE_REQUIRE(h && out, "kde_dasp_labels_device: null argument");
+    *out = h->labels.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_dasp_mean_device(kde_dasp* h, kde_superpixel** out)
+{
+    KDE_REQUIRE(h && out, "kde_dasp_mean_device: null argument");
+    *out = h->mean.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_dasp_centers_device(kde_dasp* h, kde_float3** out)
+{
+    KDE_REQUIRE(h && out, "kde_dasp_centers_device: null argument");
+    *out = h->centers.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_dasp_ld_device(kde_dasp* h, kde_label_distance** out)
+{
+    KDE_REQUIRE(h && out, "kde_dasp_ld_device: null argument");
+    *out = h->ld.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_dasp_labels_host(kde_dasp* h, void* stream, const int32_t** out)
+{
+    KDE_REQUIRE(h && out, "kde_dasp_labels_host: null argument");
+    const size_t px = (size_t)h->width * h->height;
+    KDE_TRY(h->labels_host.ensure(px));
+    KDE_HIP_TRY(hipMemcpyAsync(h->labels_host.p, h->labels.p, px * sizeof(int32_t), hipMemcpyDeviceToHost, as_stream(stream)));
+    KDE_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    *out = h->labels_host.p;
+    return KDE_OK;
+}
+
+// =====================================================================================================
+// EdgeRefinedSuperpixel
+// =====================================================================================================
+struct kde_ers {
+    int width, height;
+    static constexpr int WindowSize = 7;            // EdgeRefinedSuperpixel.cpp:4
+    static constexpr float SpatialSigma = 30.0f;    // :5
+    static constexpr float ColorSigma = 50.0f;      // :6
+    static constexpr float DepthSigma = 70.0f;      // :7
+    DevBuf<float> s_eff;                  // SpatialFilter_Device
+    DevBuf<int32_t> labels_a, labels_b;   // refinedLabels_Device + phase scratch
+    DevBuf<float> depth_a, depth_b;       // K9 phase buffers
+    DevBuf<float> refined_depth;          // refinedDepth_Device
+    PinnedBuf<int32_t> labels_host;
+    PinnedBuf<float> depth_host;
+    float exp_zero = 0;
+};
+
+extern "C" int kde_ers_create(kde_ers** out, int width, int height)
+{
+    KDE_REQUIRE(out, "kde_ers_create: null out");
+    *out = nullptr;
+    KDE_REQUIRE(width >= 1 && height >= 1 && (long long)width * height <= (1ll << 30), "kde_ers_create: bad size");
+    kde_ers* h = new (std::nothrow) kde_ers;
+    if (!h) return fail(KDE_ERR_NOMEM, "kde_ers_create: out of host memory");
+    h->width = width;
+    h->height = height;
+    h->exp_zero = exp_zero_threshold();
+    const size_t px = (size_t)width * height;
+    float table[49];
+    spatial_table(kde_ers::WindowSize, kde_ers::SpatialSigma, table);
+    for (float& v : table)
+        if (v == 0.0f) v = 1.0f;
+    int rc = h->s_eff.alloc(49);
+    if (rc == KDE_OK) rc = h->labels_a.alloc(px);
+    if (rc == KDE_OK) rc = h->labels_b.alloc(px);
+    if (rc == KDE_OK) rc = h->depth_a.alloc(px);
+    if (rc == KDE_OK) rc = h->depth_b.alloc(px);
+    if (rc == KDE_OK) rc = h->refined_depth.alloc(px);
+    if (rc == KDE_OK && hipMemcpy(h->s_eff.p, table, sizeof(table), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(KDE_ERR_HIP, "kde_ers_create: table upload failed");
+    if (rc != KDE_OK) { delete h; return rc; }
+    *out = h;
+    return KDE_OK;
+}
+
+extern "C" int kde_ers_destroy(kde_ers* h) { delete h; return KDE_OK; }
+
+extern "C" int kde_ers_edge_refining(kde_ers* h, const int32_t* color_labels_dev, const int32_t* depth_labels_dev,
+                                     const float* depth_dev, const uint8_t* bgr_dev, void* stream)
+{
+    KDE_REQUIRE(h && color_labels_dev && depth_labels_dev && depth_dev && bgr_dev, "kde_ers_edge_refining: null argument");
+    hipStream_t s = as_stream(stream);
+    const int W = h->width, H = h->height;
+    // EdgeRefinedSuperpixel.cu:210-211 copies labels/depth, then edge_refining works in place; here the
+    // horizontal phase reads the caller's buffers and the vertical phase reads the horizontal result,
+    // so the two D2D copies disappear.
+    KDE_TRY(launch_ers_edge_phase(W, H, 0, kde_ers::WindowSize, color_labels_dev, depth_labels_dev, depth_dev,
+                                  h->labels_b.p, h->depth_b.p, s));
+    KDE_TRY(launch_ers_edge_phase(W, H, 1, kde_ers::WindowSize, color_labels_dev, h->labels_b.p, h->depth_b.p,
+                                  h->labels_a.p, h->depth_a.p, s));
+    // depthmap_enhancement (.cu:220-221)
+    KDE_TRY(launch_ers_enhance(W, H, h->depth_a.p, bgr_dev, h->labels_a.p, h->s_eff.p, kde_ers::WindowSize,
+                               kde_ers::ColorSigma, kde_ers::DepthSigma, h->exp_zero, h->refined_depth.p, s));
+    return KDE_OK;
+}
+
+extern "C" int kde_ers_stage_edge_depth_device(kde_ers* h, float** out)
+{
+    KDE_REQUIRE(h && out, "kde_ers_stage_edge_depth_device: null argument");
+    *out = h->depth_a.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_ers_refined_labels_device(kde_ers* h, int32_t** out)
+{
+    KDE_REQUIRE(h && out, "kde_ers_refined_labels_device: null argument");
+    *out = h->labels_a.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_ers_refined_depth_device(kde_ers* h, float** out)
+{
+    KDE_REQUIRE(h && out, "kde_ers_refined_depth_device: null argument");
+    *out = h->refined_depth.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_ers_refined_labels_host(kde_ers* h, void* stream, const int32_t** out)
+{
+    KDE_REQUIRE(h && out, "kde_ers_refined_labels_host: null argument");
+    const size_t px = (size_t)h->width * h->height;
+    KDE_TRY(h->labels_host.ensure(px));
+    KDE_HIP_TRY(hipMemcpyAsync(h->labels_host.p, h->labels_a.p, px * sizeof(int32_t), hipMemcpyDeviceToHost, as_stream(stream)));
+    KDE_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    *out = h->labels_host.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_ers_refined_depth_host(kde_ers* h, void* stream, const float** out)
+{
+    KDE_REQUIRE(h && out, "kde_ers_refined_depth_host: null argument");
+    const size_t px = (size_t)h->width * h->height;
+    KDE_TRY(h->depth_host.ensure(px));
+    KDE_HIP_TRY(hipMemcpyAsync(h->depth_host.p, h->refined_depth.p, px * sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
+    KDE_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    *out = h->depth_host.p;
+    return KDE_OK;
+}
+
+// =====================================================================================================
+// RegionGrowingBilateralFilter / SPDepthSuperResolution (pipeline objects)
+// =====================================================================================================
+struct Pipeline {
+    int width = 0, height = 0;
+    kde_dasp* SP = nullptr;     // colour segmentation
+    kde_dasp* DASP = nullptr;   // depth-adaptive segmentation
+    kde_ers* ERS = nullptr;
+    ~Pipeline()
+    {
+        kde_dasp_destroy(SP);
+        kde_dasp_destroy(DASP);
+        kde_ers_destroy(ERS);
+    }
+    int init(int w, int h)
+    {
+        width = w;
+        height = h;
+        KDE_TRY(kde_dasp_create(&DASP, w, h));
+        KDE_TRY(kde_dasp_create(&SP, w, h));
+        KDE_TRY(kde_ers_create(&ERS, w, h));
+        return KDE_OK;
+    }
+    int run(const float* depth, const kde_float3* pts, const uint8_t* bgr, float c1, float s1, float d1, float c2,
+            float s2, float d2, int iters, void* stream)
+    {
+        KDE_TRY(kde_dasp_segmentation(SP, bgr, pts, c1, s1, d1, iters, stream));
+        KDE_TRY(kde_dasp_segmentation(DASP, bgr, pts, c2, s2, d2, iters, stream));
+        return kde_ers_edge_refining(ERS, SP->labels.p, DASP->labels.p, depth, bgr, stream);
+    }
+};
+
+struct kde_rgbf {
+    Pipeline p;
+};
+
+extern "C" int kde_rgbf_create(kde_rgbf** out, int width, int height)
+{
+    KDE_REQUIRE(out, "kde_rgbf_create: null out");
+    *out = nullptr;
+    kde_rgbf* h = new (std::nothrow) kde_rgbf;
+    if (!h) return fail(KDE_ERR_NOMEM, "kde_rgbf_create: out of host memory");
+    int rc = h->p.init(width, height);
+    if (rc != KDE_OK) { delete h; return rc; }
+    *out = h;
+    return KDE_OK;
+}
+
+extern "C" int kde_rgbf_destroy(kde_rgbf* h) { delete h; return KDE_OK; }
+
+extern "C" int kde_rgbf_set_parameters(kde_rgbf* h, int rows, int cols, const double* K)
+{
+    KDE_REQUIRE(h, "kde_rgbf_set_parameters: null handle");
+    KDE_TRY(kde_dasp_set_parameters(h->p.SP, rows, cols, K));      // RegionGrowingBilateralFilter.cpp:24
+    return kde_dasp_set_parameters(h->p.DASP, rows, cols, K);      // :25
+}
+
+extern "C" int kde_rgbf_process(kde_rgbf* h, const float* depth_dev, const kde_float3* points_dev, const uint8_t* bgr_dev, void* stream)
+{
+    KDE_REQUIRE(h && depth_dev && points_dev && bgr_dev, "kde_rgbf_process: null argument");
+    // RegionGrowingBilateralFilter.cpp:28-31
+    return h->p.run(depth_dev, points_dev, bgr_dev, 200.0f, 40.0f, 0.0f, 100.0f, 20.0f, 200.0f, 1, stream);
+}
+
+extern "C" int kde_rgbf_refined_depth_device(kde_rgbf* h, float** out)
+{
+    KDE_REQUIRE(h, "kde_rgbf_refined_depth_device: null handle");
+    return kde_ers_refined_depth_device(h->p.ERS, out);
+}
+
+extern "C" int kde_rgbf_refined_depth_host(kde_rgbf* h, void* stream, const float** out)
+{
+    KDE_REQUIRE(h, "kde_rgbf_refined_depth_host: null handle");
+    return kde_ers_refined_depth_host(h->p.ERS, stream, out);
+}
+
+extern "C" int kde_rgbf_refined_labels_device(kde_rgbf* h, int32_t** out)
+{
+    KDE_REQUIRE(h, "kde_rgbf_refined_labels_device: null handle");
+    return kde_ers_refined_labels_device(h->p.ERS, out);
+}
+
+extern "C" int kde_rgbf_sp_labels_device(kde_rgbf* h, int32_t** out)
+{
+    KDE_REQUIRE(h, "kde_rgbf_sp_labels_device: null handle");
+    return kde_dasp_labels_device(h->p.SP, out);
+}
+
+extern "C" int kde_rgbf_dasp_labels_device(kde_rgbf* h, int32_t** out)
+{
+    KDE_REQUIRE(h, "kde_rgbf_dasp_labels_device: null handle");
+    return kde_dasp_labels_device(h->p.DASP, out);
+}
+
+struct kde_spdsr {
+    Pipeline p;
+    kde_dimconv conv;
+    DevBuf<kde_float3> edge_points;   // EdgeEnhanced3DPoints_Device
+};
+
+extern "C" int kde_spdsr_create(kde_spdsr** out, int width, int height)
+{
+    KDE_REQUIRE(out, "kde_spdsr_create: null out");
+    *out = nullptr;
+    kde_spdsr* h = new (std::nothrow) kde_spdsr;
+    if (!h) return fail(KDE_ERR_NOMEM, "kde_spdsr_create: out of host memory");
+    int rc = h->p.init(width, height);
+    if (rc == KDE_OK) rc = h->edge_points.alloc((size_t)width * height);   // SPDepthSuperResolution.cpp:19
+    if (rc != KDE_OK) { delete h; return rc; }
+    *out = h;
+    return KDE_OK;
+}
+
+extern "C" int kde_spdsr_destroy(kde_spdsr* h) { delete h; return KDE_OK; }
+
+extern "C" int kde_spdsr_set_parameters(kde_spdsr* h, int rows, int cols, const double* K)
+{
+    KDE_REQUIRE(h, "kde_spdsr_set_parameters: null handle");
+    KDE_TRY(kde_dasp_set_parameters(h->p.SP, rows, cols, K));       // SPDepthSuperResolution.cpp:46
+    KDE_TRY(kde_dasp_set_parameters(h->p.DASP, rows, cols, K));     // :47
+    return kde_dimconv_set_camera(&h->conv, K, h->p.width, h->p.height);   // :48
+}
+
+extern "C" int kde_spdsr_process(kde_spdsr* h, const float* depth_dev, const kde_float3* points_dev, const uint8_t* bgr_dev, void* stream)
+{
+    KDE_REQUIRE(h && depth_dev && points_dev && bgr_dev, "kde_spdsr_process: null argument");
+    // SPDepthSuperResolution.cpp:59-64
+    KDE_TRY(h->p.run(depth_dev, points_dev, bgr_dev, 200.0f, 10.0f, 0.0f, 0.0f, 10.0f, 200.0f, 5, stream));
+    return kde_dimconv_projective_to_real_depth(&h->conv, 1, h->p.ERS->refined_depth.p, h->edge_points.p, stream);
+}
+
+extern "C" int kde_spdsr_refined_depth_device(kde_spdsr* h, float** out)
+{
+    KDE_REQUIRE(h, "kde_spdsr_refined_depth_device: null handle");
+    return kde_ers_refined_depth_device(h->p.ERS, out);
+}
+
+extern "C" int kde_spdsr_refined_depth_host(kde_spdsr* h, void* stream, const float** out)
+{
+    KDE_REQUIRE(h, "kde_spdsr_refined_depth_host: null handle");
+    return kde_ers_refined_depth_host(h->p.ERS, stream, out);
+}
+
+extern "C" int kde_spdsr_refined_labels_device(kde_spdsr* h, int32_t** out)
+{
+    KDE_REQUIRE(h, "kde_spdsr_refined_labels_device: null handle");
+    return kde_ers_refined_labels_device(h->p.ERS, out);
+}
+
+extern "C" int kde_spdsr_edge_enhanced_points_device(kde_spdsr* h, kde_float3** out)
+{
+    KDE_REQUIRE(h && out, "kde_spdsr_edge_enhanced_points_device: null argument");
+    *out = h->edge_points.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_spdsr_optimized_points_device(kde_spdsr* h, kde_float3** out)
+{
+    (void)h;
+    if (out) *out = nullptr;
+    return fail(KDE_ERR_UNSUPPORTED,
+                "getOptimizedPoints: the PCA + plane-projection tail (SPDepthSuperResolution.cpp:65-190) is not built yet");
+}
+
+// =====================================================================================================
+// measurement helper
+// =====================================================================================================
+extern "C" int kde_bench_copy(const void* src_dev, void* dst_dev, size_t bytes, void* stream)
+{
+    KDE_REQUIRE(src_dev && dst_dev, "kde_bench_copy: null argument");
+    KDE_REQUIRE(aligned16(src_dev) && aligned16(dst_dev), "kde_bench_copy: pointers must be 16-byte aligned");
+    return launch_copy(src_dev, dst_dev, bytes, as_stream(stream));
+}

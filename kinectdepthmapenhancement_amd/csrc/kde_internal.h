@@ -1,0 +1,179 @@
+// kde_internal.h — shared host-side plumbing of libkde_hip.so (not part of the public ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/kde_hip.h"
+
+namespace kde {
+
+// ---- error reporting -----------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define KDE_HIP_TRY(expr)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return ::kde::fail(KDE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                               __FILE__, __LINE__);                                           \
+    } while (0)
+
+#define KDE_TRY(expr)                \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != KDE_OK) return rc_; \
+    } while (0)
+
+#define KDE_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) return ::kde::fail(KDE_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Device buffer with RAII; never throws.
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count)
+    {
+        release();
+        if (count == 0) return KDE_OK;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(KDE_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        }
+        n = count;
+        return KDE_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// Pinned host buffer (the reference's cudaMallocHost'ed *_Host members), allocated lazily.
+template <typename T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count)
+    {
+        if (p && n >= count) return KDE_OK;
+        release();
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), count * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(KDE_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        }
+        n = count;
+        return KDE_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~PinnedBuf() { release(); }
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+};
+
+// ---- exp() underflow thresholds (the reference's "skip the factor if it is exactly 0" rule) --
+// smallest float x with exp(-x) rounding to 0 in IEEE binary32 (round to nearest): x > 150*ln2
+float exp_zero_threshold();
+// spatial table of calcSpatialFilter (JointBilateralFilter.cpp:31-40 / EdgeRefinedSuperpixel.cpp:46-55)
+void spatial_table(int window, float sigma, float* table);
+
+// ---- launchers implemented in the .hip translation units ------------------------------------
+struct JbfLaunch {
+    int width, height, n;
+    int window;
+    const float* depth;        // [n][H][W]
+    const uint8_t* guide;      // [n][H][W][3]
+    float* out;                // [n][H][W]
+    const float* s_eff;        // device, window^2 (zeros replaced by 1)
+    float color_sigma, depth_sigma;
+    float color_den, depth_den;    // 2*sigma^2 as the reference forms it (float)
+    int cd_skip;               // colour factor skipped (== underflow to 0) when cd >= cd_skip
+    float d2_skip;             // depth factor skipped when (d_q - wavg)^2 >= d2_skip
+    int variant;
+};
+int launch_jbf(const JbfLaunch& a, hipStream_t s);
+int jbf_variant_count();
+const char* jbf_variant_name(int v);
+
+struct PresmoothLaunch {
+    int width, height, n;
+    int radius;                // ksz/2 after OpenCV's adjustment
+    const uint8_t* src;        // [n][H][W][3]
+    uint8_t* dst;
+    const float* lut;          // device, (radius^2+1) x 766 weights
+};
+int launch_presmooth(const PresmoothLaunch& a, hipStream_t s);
+
+struct MrfLaunch {
+    int width, height, n, window;
+    const float* depth;
+    const uint8_t* bgr;
+    float* out;
+    float color_sigma, smooth_sigma;
+};
+int launch_mrf(const MrfLaunch& a, hipStream_t s);
+
+struct Camera {
+    float fx, fy;
+    int cx, cy;
+    int width, height;
+};
+int launch_p2r_depth(const Camera& c, int n, const float* depth, kde_float3* out, hipStream_t s);
+int launch_p2r_points(const Camera& c, int n, const kde_float3* in, kde_float3* out, hipStream_t s);
+int launch_p2r_interp(const Camera& c, int n, const float* depth, kde_float3* out, hipStream_t s);
+int launch_r2p(const Camera& c, int n, const kde_float3* in, kde_float3* out, hipStream_t s);
+
+int launch_buf_init(kde_weighted_d* buf, size_t n, hipStream_t s);
+int launch_buf_insert_depth(kde_weighted_d* buf, const float* d, size_t n, hipStream_t s);
+int launch_buf_insert_float2(kde_weighted_d* buf, const float* xy, int width, int height, hipStream_t s);
+int launch_buf_get(const kde_weighted_d* buf, float* out, size_t n, int which, hipStream_t s);
+int launch_buf_update(kde_weighted_d* buf, const float* d, size_t n, int n_frames, hipStream_t s);
+int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
+
+struct DaspGeom {
+    int width, height, rows, cols, wx, wy;
+};
+int launch_dasp_init_ld(const DaspGeom& g, kde_label_distance* ld, hipStream_t s);
+int launch_dasp_sample(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
+                       kde_float3* centers, hipStream_t s);
+int launch_dasp_calc_ld(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld,
+                        const kde_superpixel* mean, const kde_float3* centers, int32_t* labels, float color_sigma,
+                        float spatial_sigma, float depth_sigma, hipStream_t s);
+int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const kde_label_distance* ld,
+                        kde_superpixel* mean, kde_float3* centers, const float* intr_dev, hipStream_t s);
+
+int launch_ers_edge_phase(int width, int height, int dir, int window, const int32_t* color_labels, const int32_t* l0,
+                          const float* d0, int32_t* l1, float* d1, hipStream_t s);
+int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr, const int32_t* labels,
+                       const float* s_eff, int window, float color_sigma, float depth_sigma, float exp_zero,
+                       float* out, hipStream_t s);
+
+}  // namespace kde

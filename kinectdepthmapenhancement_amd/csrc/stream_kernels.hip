@@ -1,0 +1,326 @@
+// stream_kernels.hip — the HBM-bound element-wise feeders of the hot path:
+//   DimensionConvertor (K2/K3): DimensionConvertor/DimensionConvertor.h:19-148, .cu:3-77
+//   Buffer2D (K4):              ArrayBuffer/ArrayBuffer.cu:9-22, ArrayBuffer/Buffer2D.cu:13-147
+// One grid-stride pass each, 16-byte accesses where the record layout allows it; the reference's
+// redundant thrust::fill before every projectiveToReal (DimensionConvertor.cu:5-13) is not reproduced
+// (every output element is overwritten).
+#include "kde_internal.h"
+
+namespace kde {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 256 * 8;   // 256 CUs x 8 workgroups, grid-stride beyond that
+
+inline int grid_for(size_t items)
+{
+    size_t b = (items + kThreads - 1) / kThreads;
+    if (b < 1) b = 1;
+    if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+    return (int)b;
+}
+
+// ---- DimensionConvertor ---------------------------------------------------------------------
+__device__ __forceinline__ void convert_ptr(float& x, float& y, float z, const Camera& c)
+{
+    // DimensionConvertor.h:34-48 — subtract, divide, multiply (in that order)
+    y = (float)c.cy - y;
+    x = x - (float)c.cx;
+    x /= c.fx;
+    y /= c.fy;
+    x *= z;
+    y *= z;
+}
+
+// Four pixels per thread: one float4 depth load, three float4 stores (48 B = 4 packed float3).
+// blockIdx.y = frame; the in-frame index is 32-bit so one division serves four pixels.
+__device__ __forceinline__ void p2r_one(const Camera& c, int interp, unsigned x, unsigned y, float z, float* r)
+{
+    float fx_, fy_;
+    if (!interp) {
+        // convert_ptr(tuple<float,int>), DimensionConvertor.h:51-62
+        fy_ = (float)(int)y;
+        fx_ = (float)(int)x;
+        convert_ptr(fx_, fy_, z, c);
+    } else {
+        // convert_ptr_int, DimensionConvertor.h:80-103 (half-pixel grid, index decomposed over 2*width)
+        fy_ = (float)(int)y;
+        fx_ = (float)(int)x;
+        fy_ = (float)c.cy - fy_ / 2.0f;
+        fx_ = fx_ / 2.0f - (float)c.cx;
+        fx_ /= c.fx;
+        fy_ /= c.fy;
+        fx_ *= z;
+        fy_ *= z;
+    }
+    r[0] = fx_;
+    r[1] = fy_;
+    r[2] = z;
+}
+
+__global__ __launch_bounds__(kThreads) void p2r_depth_kernel(Camera c, const float* __restrict__ depth_all,
+                                                            float* __restrict__ out_all, int interp)
+{
+    const unsigned frame_px = (unsigned)c.width * (unsigned)c.height;
+    const unsigned row = interp ? (unsigned)c.width * 2u : (unsigned)c.width;
+    const float* __restrict__ depth = depth_all + (size_t)blockIdx.y * frame_px;
+    float* __restrict__ out = out_all + (size_t)blockIdx.y * frame_px * 3;
+    const unsigned groups = frame_px / 4;
+    const unsigned stride = gridDim.x * kThreads;
+    for (unsigned g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+        const float4 z4 = reinterpret_cast<const float4*>(depth)[g];
+        const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+        float r[12];
+        unsigned y = (g * 4) / row, x = (g * 4) - y * row;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            p2r_one(c, interp, x, y, z[k], r + 3 * k);
+            if (++x == row) {
+                x = 0;
+                ++y;
+            }
+        }
+        float4* o = reinterpret_cast<float4*>(out) + (size_t)g * 3;
+        o[0] = make_float4(r[0], r[1], r[2], r[3]);
+        o[1] = make_float4(r[4], r[5], r[6], r[7]);
+        o[2] = make_float4(r[8], r[9], r[10], r[11]);
+    }
+    for (unsigned i = groups * 4 + blockIdx.x * kThreads + threadIdx.x; i < frame_px; i += stride) {
+        float r[3];
+        p2r_one(c, interp, i % row, i / row, depth[i], r);
+        out[3 * (size_t)i] = r[0];
+        out[3 * (size_t)i + 1] = r[1];
+        out[3 * (size_t)i + 2] = r[2];
+    }
+}
+
+// float3 -> float3 maps; 4 points (48 B) per thread as three float4.
+__global__ __launch_bounds__(kThreads) void points_map_kernel(Camera c, size_t total, const float* __restrict__ in,
+                                                             float* __restrict__ out, int to_projective)
+{
+    const size_t groups = total / 4;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    auto map = [&](float& x, float& y, float& z) {
+        if (!to_projective) {
+            convert_ptr(x, y, z, c);          // DimensionConvertor.cu:25-33
+        } else {
+            // convert_rtp, DimensionConvertor.h:128-147
+            if (fabsf(z) < 1.0f) {
+                x = -1.0f;
+                y = -1.0f;
+            } else {
+                float ox = x / z, oy = y / z;
+                ox *= c.fx;
+                oy *= c.fy;
+                x = ox + (float)c.cx;
+                y = (float)c.cy - oy;
+            }
+        }
+    };
+    for (size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+        const float4* p = reinterpret_cast<const float4*>(in) + g * 3;
+        float4 a = p[0], b = p[1], d = p[2];
+        float r[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) map(r[3 * k], r[3 * k + 1], r[3 * k + 2]);
+        float4* o = reinterpret_cast<float4*>(out) + g * 3;
+        o[0] = make_float4(r[0], r[1], r[2], r[3]);
+        o[1] = make_float4(r[4], r[5], r[6], r[7]);
+        o[2] = make_float4(r[8], r[9], r[10], r[11]);
+    }
+    for (size_t i = groups * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += stride) {
+        float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+        map(x, y, z);
+        out[3 * i] = x;
+        out[3 * i + 1] = y;
+        out[3 * i + 2] = z;
+    }
+}
+
+// ---- Buffer2D -------------------------------------------------------------------------------
+__device__ __forceinline__ int f2i_rz(float v) { return (int)v; }   // v_cvt_i32_f32: RZ, saturating, NaN -> 0
+
+__device__ __forceinline__ void update_weighted_depth(float& rd, float& rw, float d)
+{
+    // updateWaitedDepth, ArrayBuffer/Buffer2D.cu:13-30
+    if (d > 50.0f) {
+        if (rd != 0.0f) {
+            int diff = f2i_rz(rd) - f2i_rz(d);
+            if (diff < 0) diff = -diff;
+            if ((float)diff < d * 0.01f) {
+                rd = ((rd * (rw + 1.0f)) + (d * rw)) / (rw * 2.0f + 1.0f);
+                rw = rw + 1.0f;
+            }
+        } else {
+            rd = d;
+            rw = 1.0f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void buf_fill_kernel(float4* __restrict__ buf, size_t n4, float2* tail, size_t ntail)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride)
+        buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < ntail; i += stride) tail[i] = make_float2(0.f, 0.f);
+}
+
+// two records (16 B) per thread
+__global__ __launch_bounds__(kThreads) void buf_insert_depth_kernel(kde_weighted_d* __restrict__ buf,
+                                                                   const float* __restrict__ d, size_t n)
+{
+    const size_t pairs = n / 2;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x; g < pairs; g += stride) {
+        const float2 v = reinterpret_cast<const float2*>(d)[g];
+        reinterpret_cast<float4*>(buf)[g] = make_float4(v.x, 1.0f, v.y, 1.0f);   // Buffer2D.cu:45-48
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
+        buf[n - 1].d = d[n - 1];
+        buf[n - 1].w = 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void buf_insert_float2_kernel(kde_weighted_d* __restrict__ buf,
+                                                                    const float2* __restrict__ xy, int width, int height)
+{
+    const size_t n = (size_t)width * height;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const int y = (int)(i / width);
+        kde_weighted_d r;
+        r.d = xy[i].x;
+        r.w = (float)y;   // sic: Buffer2D.cu:137 stores the row index
+        buf[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void buf_get_kernel(const kde_weighted_d* __restrict__ buf, float* __restrict__ out,
+                                                          size_t n, int which)
+{
+    const size_t pairs = n / 2;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x; g < pairs; g += stride) {
+        const float4 v = reinterpret_cast<const float4*>(buf)[g];
+        reinterpret_cast<float2*>(out)[g] = which ? make_float2(v.y, v.w) : make_float2(v.x, v.z);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) out[n - 1] = which ? buf[n - 1].w : buf[n - 1].d;
+}
+
+// updateData over n_frames consecutive frames fused into one read-modify-write of the buffer
+__global__ __launch_bounds__(kThreads) void buf_update_kernel(kde_weighted_d* __restrict__ buf, const float* __restrict__ d,
+                                                             size_t n, int n_frames)
+{
+    const size_t pairs = n / 2;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x; g < pairs; g += stride) {
+        float4 r = reinterpret_cast<float4*>(buf)[g];
+        for (int f = 0; f < n_frames; f++) {
+            const float2 v = reinterpret_cast<const float2*>(d + (size_t)f * n)[g];
+            update_weighted_depth(r.x, r.y, v.x);
+            update_weighted_depth(r.z, r.w, v.y);
+        }
+        reinterpret_cast<float4*>(buf)[g] = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
+        float rd = buf[n - 1].d, rw = buf[n - 1].w;
+        for (int f = 0; f < n_frames; f++) update_weighted_depth(rd, rw, d[(size_t)f * n + n - 1]);
+        buf[n - 1].d = rd;
+        buf[n - 1].w = rw;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+}  // namespace
+
+int launch_p2r_depth(const Camera& c, int n, const float* depth, kde_float3* out, hipStream_t s)
+{
+    const size_t frame_px = (size_t)c.width * c.height;
+    hipLaunchKernelGGL(p2r_depth_kernel, dim3(grid_for(frame_px / 4 + 1), n), dim3(kThreads), 0, s, c, depth,
+                       reinterpret_cast<float*>(out), 0);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_p2r_interp(const Camera& c, int n, const float* depth, kde_float3* out, hipStream_t s)
+{
+    const size_t frame_px = (size_t)c.width * c.height;
+    hipLaunchKernelGGL(p2r_depth_kernel, dim3(grid_for(frame_px / 4 + 1), n), dim3(kThreads), 0, s, c, depth,
+                       reinterpret_cast<float*>(out), 1);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_p2r_points(const Camera& c, int n, const kde_float3* in, kde_float3* out, hipStream_t s)
+{
+    const size_t total = (size_t)c.width * c.height * n;
+    hipLaunchKernelGGL(points_map_kernel, dim3(grid_for(total / 4 + 1)), dim3(kThreads), 0, s, c, total,
+                       reinterpret_cast<const float*>(in), reinterpret_cast<float*>(out), 0);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_r2p(const Camera& c, int n, const kde_float3* in, kde_float3* out, hipStream_t s)
+{
+    const size_t total = (size_t)c.width * c.height * n;
+    hipLaunchKernelGGL(points_map_kernel, dim3(grid_for(total / 4 + 1)), dim3(kThreads), 0, s, c, total,
+                       reinterpret_cast<const float*>(in), reinterpret_cast<float*>(out), 1);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_buf_init(kde_weighted_d* buf, size_t n, hipStream_t s)
+{
+    const size_t n4 = n / 2;
+    hipLaunchKernelGGL(buf_fill_kernel, dim3(grid_for(n4 + 1)), dim3(kThreads), 0, s, reinterpret_cast<float4*>(buf), n4,
+                       reinterpret_cast<float2*>(buf) + n4 * 2, n - n4 * 2);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_buf_insert_depth(kde_weighted_d* buf, const float* d, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(buf_insert_depth_kernel, dim3(grid_for(n / 2 + 1)), dim3(kThreads), 0, s, buf, d, n);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_buf_insert_float2(kde_weighted_d* buf, const float* xy, int width, int height, hipStream_t s)
+{
+    hipLaunchKernelGGL(buf_insert_float2_kernel, dim3(grid_for((size_t)width * height)), dim3(kThreads), 0, s, buf,
+                       reinterpret_cast<const float2*>(xy), width, height);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_buf_get(const kde_weighted_d* buf, float* out, size_t n, int which, hipStream_t s)
+{
+    hipLaunchKernelGGL(buf_get_kernel, dim3(grid_for(n / 2 + 1)), dim3(kThreads), 0, s, buf, out, n, which);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_buf_update(kde_weighted_d* buf, const float* d, size_t n, int n_frames, hipStream_t s)
+{
+    hipLaunchKernelGGL(buf_update_kernel, dim3(grid_for(n / 2 + 1)), dim3(kThreads), 0, s, buf, d, n, n_frames);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s)
+{
+    if (bytes % 16 != 0) return fail(KDE_ERR_INVALID, "kde_bench_copy: bytes must be a multiple of 16");
+    const size_t n4 = bytes / 16;
+    hipLaunchKernelGGL(copy_kernel, dim3(grid_for(n4)), dim3(kThreads), 0, s, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), n4);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+}  // namespace kde

@@ -1,0 +1,920 @@
+/*
+ * oracle/kde_oracle.c — CPU restatement of the reference hot path (see kde_oracle.h).
+ *
+ * TEST INFRASTRUCTURE ONLY — PARITY UNPINNED (no reference fixtures exist).
+ * Every function cites the reference file:line it restates.  Build:
+ *     gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -fPIC -shared (oracle/Makefile)
+ *
+ * Deviations from the literal CUDA text (shared verbatim with the HIP kernels):
+ *   D1  sampleInitialClusters taps with a negative linear index read colour (0,0,0)
+ *       (reference reads before the buffer: DepthAdaptiveSuperpixel.cu:52-54).
+ *   D2  edge_refining uses snapshot semantics per phase (reference is racy in place).
+ *   D3  depthmap_enhancement reads the phase-start depth and writes a separate buffer.
+ *   D4  every grid is ceil-div + bounds-guarded (reference drops partial tiles).
+ *   Q3  depth_sigma == 0 leaves depth_filter uninitialised in the reference: factor skipped.
+ *   float->int conversions follow CUDA's cvt.rzi.s32.f32 (saturating, NaN -> 0).
+ */
+#include "kde_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_threads = 1;
+
+int okde_set_threads(int n)
+{
+    int prev = g_threads;
+    g_threads = n < 1 ? 1 : n;
+    return prev;
+}
+
+int okde_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* CUDA float -> int (round toward zero, saturating, NaN -> 0) */
+static int f2i_rz(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * JointBilateralFilter::calcSpatialFilter — JointBilateralFilter/JointBilateralFilter.cpp:31-40
+ * (identical text in EdgeRefinedSuperpixel/EdgeRefinedSuperpixel.cpp:46-55)
+ * ---------------------------------------------------------------------------------------- */
+void okde_spatial_table(int window, float sigma, float* table)
+{
+    for (int i = 0; i < window; i++) {
+        for (int j = 0; j < window; j++) {
+            float fx = (float)(j - window / 2);
+            float fy = (float)(i - window / 2);
+            float dis_x = fx * fx;
+            float dis_y = fy * fy;
+            table[i * window + j] = expf(-(dis_x + dis_y) / (2.0f * (sigma * sigma)));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K0 — cv::gpu::bilateralFilter, OpenCV 2.4.3 gpu module (third party, not under
+ * /root/reference; restated from its published algorithm: modules/gpu/src/denoising.cpp
+ * + src/cuda/bilateral_filter.cu).  Call site: JointBilateralFilter.cu:285 with
+ * (kernel_size=5, sigma_color=30, sigma_spatial=30, BORDER_DEFAULT = reflect-101).
+ * ---------------------------------------------------------------------------------------- */
+static int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+static uint8_t sat_u8_rn(float v)
+{
+    /* saturate_cast<uchar>(float) on the device: cvt.rni.sat.u8.f32 (round half to even) */
+    if (!(v > 0.0f)) return 0; /* also NaN -> 0 */
+    if (v >= 255.0f) return 255;
+    return (uint8_t)rintf(v);
+}
+
+void okde_cv_bilateral_8uc3(const uint8_t* src, int width, int height, size_t src_step,
+                            int kernel_size, float sigma_color, float sigma_spatial,
+                            uint8_t* dst, size_t dst_step)
+{
+    sigma_color = (sigma_color <= 0) ? 1 : sigma_color;
+    sigma_spatial = (sigma_spatial <= 0) ? 1 : sigma_spatial;
+    int radius = (kernel_size <= 0) ? (int)rint((double)sigma_spatial * 1.5) : kernel_size / 2;
+    int ksz = (radius > 1 ? radius : 1) * 2 + 1;
+    const float ss = -0.5f / (sigma_spatial * sigma_spatial);
+    const float sc = -0.5f / (sigma_color * sigma_color);
+    const int r = ksz / 2;
+    const float r2 = (float)(r * r);
+
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            const uint8_t* c = src + (size_t)y * src_step + (size_t)x * 3;
+            const float c0 = (float)c[0], c1 = (float)c[1], c2 = (float)c[2];
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, sum2 = 0.0f;
+            for (int cy = y - r; cy < y - r + ksz; ++cy) {
+                for (int cx = x - r; cx < x - r + ksz; ++cx) {
+                    float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
+                    if (space2 > r2) continue;
+                    const uint8_t* v = src + (size_t)reflect101(cy, height) * src_step +
+                                       (size_t)reflect101(cx, width) * 3;
+                    const float v0 = (float)v[0], v1 = (float)v[1], v2 = (float)v[2];
+                    float n1 = fabsf(v0 - c0) + fabsf(v1 - c1) + fabsf(v2 - c2);
+                    float weight = expf(space2 * ss + (n1 * n1) * sc);
+                    s0 = s0 + weight * v0;
+                    s1 = s1 + weight * v1;
+                    s2 = s2 + weight * v2;
+                    sum2 = sum2 + weight;
+                }
+            }
+            uint8_t* o = dst + (size_t)y * dst_step + (size_t)x * 3;
+            o[0] = sat_u8_rn(s0 / sum2);
+            o[1] = sat_u8_rn(s1 / sum2);
+            o[2] = sat_u8_rn(s2 / sum2);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K1 — joint_bilateral_filtering, JointBilateralFilter/JointBilateralFilter.cu:4-83
+ * ---------------------------------------------------------------------------------------- */
+static inline float color_diff3(const uint8_t* a, const uint8_t* b)
+{
+    float d0 = (float)a[0] - (float)b[0];
+    float d1 = (float)a[1] - (float)b[1];
+    float d2 = (float)a[2] - (float)b[2];
+    return d0 * d0 + d1 * d1 + d2 * d2;
+}
+
+void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* guide,
+                     const float* spatial, int window_size, float color_sigma, float depth_sigma,
+                     float* filtered, uint8_t* ill)
+{
+    const int hw = window_size / 2;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            const uint8_t* cc = guide + ((size_t)y * width + x) * 3;
+            /* calculate weighted average — .cu:16-38 */
+            float w_average = 0.0f;
+            float weight = 0.0f;
+            for (int i = -hw; i <= hw; i++) {
+                for (int j = -hw; j <= hw; j++) {
+                    int xj = x + j, yi = y + i;
+                    if (xj >= 0 && xj < width && yi >= 0 && yi < height &&
+                        depth[(size_t)yi * width + xj] > 50.0f) {
+                        float color_diff = color_diff3(cc, guide + ((size_t)yi * width + xj) * 3);
+                        float color_filter = 0.0f;
+                        if (color_sigma != 0.0f)
+                            color_filter = expf(-color_diff / (2 * (color_sigma * color_sigma)));
+                        float filter = 1.0f;
+                        float s = spatial[(i + hw) * window_size + (j + hw)];
+                        if (s != 0.0f) filter *= s;
+                        if (color_filter != 0.0f) filter *= color_filter;
+                        w_average += depth[(size_t)yi * width + xj] * filter;
+                        weight += filter;
+                    }
+                }
+            }
+            float out = 0.0f;
+            uint8_t flag = 0;
+            if (weight > 0.0f) {
+                w_average /= weight;
+                /* filtering — .cu:43-78 */
+                float numerator = 0.0f, denominator = 0.0f;
+                for (int i = -hw; i <= hw; i++) {
+                    for (int j = -hw; j <= hw; j++) {
+                        int xj = x + j, yi = y + i;
+                        if (xj >= 0 && xj < width && yi >= 0 && yi < height &&
+                            depth[(size_t)yi * width + xj] > 50.0f) {
+                            float dq = depth[(size_t)yi * width + xj];
+                            float color_diff = color_diff3(cc, guide + ((size_t)yi * width + xj) * 3);
+                            float color_filter = 0.0f;
+                            if (color_sigma != 0.0f)
+                                color_filter = expf(-color_diff / (2 * (color_sigma * color_sigma)));
+                            float dd = dq - w_average;
+                            float depth_diff = dd * dd;
+                            float depth_filter = 0.0f; /* Q3: uninitialised in the reference */
+                            if (depth_sigma != 0.0f)
+                                depth_filter = expf(-depth_diff / (2.0f * (depth_sigma * depth_sigma)));
+                            float filter = 1.0f;
+                            float s = spatial[(i + hw) * window_size + (j + hw)];
+                            if (s != 0.0f) filter *= s;
+                            if (color_filter != 0.0f) filter *= color_filter;
+                            if (depth_filter != 0.0f) filter *= depth_filter;
+                            numerator += dq * filter;
+                            denominator += filter;
+                        }
+                    }
+                }
+                if (denominator == 0.0f) out = 0.0f;
+                else out = numerator / denominator;
+                if (denominator < 1e-30f) flag = 1;
+            }
+            filtered[(size_t)y * width + x] = out;
+            if (ill) ill[(size_t)y * width + x] = flag;
+        }
+    }
+}
+
+/* JointBilateralFilter::Process — JointBilateralFilter.cu:283-290 */
+void okde_jbf_process(int width, int height, const float* depth, const uint8_t* bgr,
+                      int window, float spatial_sigma, float color_sigma, float depth_sigma,
+                      int presmooth_ksize, float presmooth_sigma_color, float presmooth_sigma_spatial,
+                      uint8_t* smooth_out, float* filtered, uint8_t* ill)
+{
+    float* table = (float*)malloc(sizeof(float) * (size_t)window * window);
+    okde_spatial_table(window, spatial_sigma, table);
+    const uint8_t* guide = bgr;
+    uint8_t* tmp = NULL;
+    if (presmooth_ksize > -1000) {
+        uint8_t* sm = smooth_out;
+        if (!sm) sm = tmp = (uint8_t*)malloc((size_t)width * height * 3);
+        okde_cv_bilateral_8uc3(bgr, width, height, (size_t)width * 3, presmooth_ksize,
+                               presmooth_sigma_color, presmooth_sigma_spatial, sm, (size_t)width * 3);
+        guide = sm;
+    } else if (smooth_out) {
+        memcpy(smooth_out, bgr, (size_t)width * height * 3);
+    }
+    okde_jbf_kernel(width, height, depth, guide, table, window, color_sigma, depth_sigma, filtered, ill);
+    free(tmp);
+    free(table);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * markov_random_field — MarkovRandomField/MarkovRandomField.cu:4-40 (next-row f1)
+ * constants MarkovRandomField.cpp:3-6: window 5, ColorSigma 50, SmoothSigma 150
+ * ---------------------------------------------------------------------------------------- */
+void okde_mrf_kernel(int width, int height, const float* depth, const uint8_t* bgr,
+                     int window_size, float color_sigma, float smooth_sigma, float* filtered)
+{
+    const int hw = window_size / 2;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            const uint8_t* cc = bgr + ((size_t)y * width + x) * 3;
+            float numerator = depth[(size_t)y * width + x], denominator = 1.0f;
+            for (int i = -hw; i <= hw; i++) {
+                for (int j = -hw; j <= hw; j++) {
+                    int xj = x + j, yi = y + i;
+                    if (xj >= 0 && xj < width && yi >= 0 && yi < height &&
+                        depth[(size_t)yi * width + xj] > 50.0f) {
+                        float color_diff = color_diff3(cc, bgr + ((size_t)yi * width + xj) * 3);
+                        float color_filter = 0.0f;
+                        if (color_sigma != 0.0f) color_filter = expf(-color_sigma * color_diff);
+                        float filter = smooth_sigma;
+                        filter *= color_filter;
+                        numerator += depth[(size_t)yi * width + xj] * filter;
+                        denominator += filter;
+                    }
+                }
+            }
+            filtered[(size_t)y * width + x] = (denominator == 0.0f) ? 0.0f : numerator / denominator;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * DimensionConvertor — functors DimensionConvertor/DimensionConvertor.h:19-148,
+ * calls DimensionConvertor.cu:3-77; cx, cy are ints (DimensionConvertor.cpp:8-9)
+ * ---------------------------------------------------------------------------------------- */
+static inline okde_float3 convert_ptr(okde_float3 in, float fx, float fy, int cx, int cy)
+{
+    /* .h:34-48 */
+    in.y = (float)cy - in.y;
+    in.x = in.x - (float)cx;
+    in.x /= fx;
+    in.y /= fy;
+    in.x *= in.z;
+    in.y *= in.z;
+    return in;
+}
+
+void okde_p2r_depth(int width, int height, float fx, float fy, int cx, int cy,
+                    const float* depth, okde_float3* out)
+{
+    /* .cu:3-23; functor .h:51-62 */
+    const int n = width * height;
+    for (int i = 0; i < n; i++) {
+        okde_float3 r;
+        r.z = depth[i];
+        r.y = (float)(i / width);
+        r.x = (float)(i % width);
+        out[i] = convert_ptr(r, fx, fy, cx, cy);
+    }
+}
+
+void okde_p2r_points(int width, int height, float fx, float fy, int cx, int cy,
+                     const okde_float3* in, okde_float3* out)
+{
+    /* .cu:25-33 */
+    const int n = width * height;
+    for (int i = 0; i < n; i++) out[i] = convert_ptr(in[i], fx, fy, cx, cy);
+}
+
+void okde_p2r_interp(int width, int height, float fx, float fy, int cx, int cy,
+                     const float* depth, okde_float3* out)
+{
+    /* .cu:44-77; functor convert_ptr_int .h:80-103 (index decomposed over 2*width) */
+    const int n = width * height;
+    for (int i = 0; i < n; i++) {
+        okde_float3 in;
+        in.z = depth[i];
+        in.y = (float)(i / (width * 2));
+        in.x = (float)(i % (width * 2));
+        in.y = (float)cy - in.y / 2.0f;
+        in.x = in.x / 2.0f - (float)cx;
+        in.x /= fx;
+        in.y /= fy;
+        in.x *= in.z;
+        in.y *= in.z;
+        out[i] = in;
+    }
+}
+
+void okde_r2p(int width, int height, float fx, float fy, int cx, int cy,
+              const okde_float3* in, okde_float3* out)
+{
+    /* .cu:35-43; functor convert_rtp .h:128-147 */
+    const int n = width * height;
+    for (int i = 0; i < n; i++) {
+        okde_float3 o;
+        if (fabsf(in[i].z) < 1.0f) {
+            o.x = -1.0f;
+            o.y = -1.0f;
+        } else {
+            o.x = in[i].x / in[i].z;
+            o.y = in[i].y / in[i].z;
+            o.x *= fx;
+            o.y *= fy;
+            o.x = o.x + (float)cx;
+            o.y = (float)cy - o.y;
+        }
+        o.z = in[i].z;
+        out[i] = o;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Buffer2D — ArrayBuffer/ArrayBuffer.cu:9-22, ArrayBuffer/Buffer2D.cu:13-147
+ * ---------------------------------------------------------------------------------------- */
+void okde_buf_init(int n, okde_weighted_d* buf)
+{
+    for (int i = 0; i < n; i++) { buf[i].d = 0.0f; buf[i].w = 0.0f; }
+}
+
+void okde_buf_insert_depth(int n, okde_weighted_d* buf, const float* data)
+{
+    /* Buffer2D.cu:33-56 */
+    for (int i = 0; i < n; i++) { buf[i].d = data[i]; buf[i].w = 1.0f; }
+}
+
+void okde_buf_insert_float2(int width, int height, okde_weighted_d* buf, const float* data_xy)
+{
+    /* Buffer2D.cu:123-147 — the weight written is the ROW INDEX (ref->w = y, :137), kept */
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            int i = x + y * width;
+            buf[i].d = data_xy[2 * i];
+            buf[i].w = (float)y;
+        }
+}
+
+void okde_buf_get_depth(int n, const okde_weighted_d* buf, float* out)
+{
+    for (int i = 0; i < n; i++) out[i] = buf[i].d; /* Buffer2D.cu:59-77 */
+}
+
+void okde_buf_get_weight(int n, const okde_weighted_d* buf, float* out)
+{
+    for (int i = 0; i < n; i++) out[i] = buf[i].w; /* Buffer2D.cu:79-94 */
+}
+
+void okde_buf_update(int n, okde_weighted_d* buf, const float* data)
+{
+    /* updateWaitedDepth, Buffer2D.cu:13-30, driven by updateDataKernel :97-120 */
+    for (int i = 0; i < n; i++) {
+        okde_weighted_d* ref = &buf[i];
+        float d = data[i];
+        if (d > 50.0f) {
+            if (ref->d != 0.0f) {
+                int diff = f2i_rz(ref->d) - f2i_rz(d);
+                if (diff < 0) diff = -diff;
+                if ((float)diff < d * 0.01f) {
+                    ref->d = ((ref->d * (ref->w + 1.0f)) + (d * ref->w)) / (ref->w * 2.0f + 1.0f);
+                    ref->w = ref->w + 1.0f;
+                }
+            } else {
+                ref->d = d;
+                ref->w = 1.0f;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * DepthAdaptiveSuperpixel — SuperpixelSegmentation/DepthAdaptiveSuperpixel.cu
+ * ---------------------------------------------------------------------------------------- */
+int okde_dasp_check_geometry(int width, int height, int rows, int cols)
+{
+    if (width < 1 || height < 1 || rows < 1 || cols < 1) return 1;
+    int wx = width / cols, wy = height / rows;   /* DepthAdaptiveSuperpixel.cpp:19-21 */
+    if (wx < 4 || wy < 4) return 1;              /* 4x4 candidates stay inside the image */
+    if (width / wx != cols) return 1;            /* mean index uses width/window_size.x (.cu:155) */
+    if (height < 6) return 1;                    /* absolute taps yy in [-5,5] stay inside the buffer */
+    return 0;
+}
+
+/* init_LD — .cu:3-14 (D4: all pixels covered) */
+void okde_dasp_init_ld(int width, int height, int rows, int cols, okde_label_distance* ld)
+{
+    int wx = width / cols, wy = height / rows;
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            ld[y * width + x].l = (y / wy) * cols + (x / wx);
+            ld[y * width + x].d = 999999.9f;
+        }
+}
+
+/* sampleInitialClusters<16> — .cu:16-165 */
+void okde_dasp_sample_clusters(int width, int height, int rows, int cols, const uint8_t* bgr,
+                               const okde_float3* points, okde_superpixel* mean, okde_float3* centers)
+{
+    const int wx = width / cols, wy = height / rows;
+    const long npix = (long)width * height;
+    for (int by = 0; by < rows; by++) {
+        for (int bx = 0; bx < cols; bx++) {
+            float gradient[16];
+            int ax[16], ay[16];
+            const int center_x = bx * wx + wx / 2;
+            const int center_y = by * wy + wy / 2;
+            for (int ty = 0; ty < 4; ty++) {
+                for (int tx = 0; tx < 4; tx++) {
+                    const int around_x = center_x + tx - 2;
+                    const int around_y = center_y + ty - 2;
+                    const int tid = ty * 4 + tx;
+                    const uint8_t* ca = bgr + ((size_t)around_y * width + around_x) * 3;
+                    float sumG = 0.0f;
+                    int count = 0;
+                    for (int yy = -5; yy <= 5; yy++) {
+                        for (int xx = -5; xx <= 5; xx++) {
+                            /* .cu:52-54: the tap index is ABSOLUTE (yy*width+xx), lx/ly unused */
+                            long idx = (long)yy * width + xx;
+                            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+                            if (idx >= 0 && idx < npix) { /* D1 */
+                                t0 = (float)bgr[idx * 3];
+                                t1 = (float)bgr[idx * 3 + 1];
+                                t2 = (float)bgr[idx * 3 + 2];
+                            }
+                            float d0 = (float)ca[0] - t0, d1 = (float)ca[1] - t1, d2 = (float)ca[2] - t2;
+                            float g = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+                            count += g > 0.0f ? 1 : 0;
+                            sumG += g;
+                        }
+                    }
+                    gradient[tid] = sumG / (float)count;
+                    ax[tid] = around_x;
+                    ay[tid] = around_y;
+                }
+            }
+            /* 16-element tree argmin, strict '>' (.cu:106-149; Q4) */
+            for (int step = 8; step >= 1; step >>= 1)
+                for (int t = 0; t < step; t++)
+                    if (gradient[t] > gradient[t + step]) {
+                        gradient[t] = gradient[t + step];
+                        ax[t] = ax[t + step];
+                        ay[t] = ay[t + step];
+                    }
+            const int id = by * (width / wx) + bx;
+            const int sx = ax[0], sy = ay[0];
+            mean[id].x = sx;
+            mean[id].y = sy;
+            mean[id].r = bgr[((size_t)sy * width + sx) * 3];
+            mean[id].g = bgr[((size_t)sy * width + sx) * 3 + 1];
+            mean[id].b = (uint8_t)(bgr[((size_t)sy * width + sx) * 3] + 2); /* sic, .cu:159 */
+            centers[id] = points[(size_t)sy * width + sx];
+        }
+    }
+}
+
+/* calculateLD<16> — .cu:167-313 */
+void okde_dasp_calculate_ld(int width, int height, int rows, int cols, const uint8_t* bgr,
+                            const okde_float3* points, okde_label_distance* ld,
+                            const okde_superpixel* mean, const okde_float3* centers, int32_t* labels,
+                            float color_sigma, float spatial_sigma, float depth_sigma)
+{
+    const int wx = width / cols, wy = height / rows;
+    const float half = (float)(wx + wy) / 2.0f;
+    const float win2 = half * half;
+    const float sum_sigma = spatial_sigma + color_sigma + depth_sigma;
+    const float rc = color_sigma / sum_sigma, rs = spatial_sigma / sum_sigma, rd = depth_sigma / sum_sigma;
+    const float kc = rc * rc, ks = rs * rs, kd = rd * rd;
+
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            const size_t p = (size_t)y * width + x;
+            const int l0 = ld[p].l;
+            const float d0 = ld[p].d;
+            const int ccx = l0 % cols, ccy = l0 / cols;
+            const uint8_t* c = bgr + p * 3;
+            const float z = points[p].z;
+            float dist[16];
+            int lab[16];
+            for (int ty = 0; ty < 4; ty++) {
+                for (int tx = 0; tx < 4; tx++) {
+                    const int tid = ty * 4 + tx;
+                    const int rx = ccx - 2 + tx, ry = ccy - 2 + ty;
+                    if (rx >= 0 && rx < cols && ry >= 0 && ry < rows) {
+                        const int id = ry * cols + rx;
+                        float e0 = (float)c[0] - (float)mean[id].r;
+                        float e1 = (float)c[1] - (float)mean[id].g;
+                        float e2 = (float)c[2] - (float)mean[id].b;
+                        float color_distance = e0 * e0 + e1 * e1 + e2 * e2;
+                        float px = (float)(x - mean[id].x), py = (float)(y - mean[id].y);
+                        float spatial_distance = sqrtf(px * px + py * py) * win2;
+                        float depth_distance = 0.0f;
+                        if (z > 50.0f && centers[id].z > 50.0f) depth_distance = fabsf(z - centers[id].z);
+                        dist[tid] = color_distance * kc + spatial_distance * ks + depth_distance * kd;
+                        lab[tid] = id;
+                    } else {
+                        dist[tid] = d0;
+                        lab[tid] = l0;
+                    }
+                }
+            }
+            for (int step = 8; step >= 1; step >>= 1)
+                for (int t = 0; t < step; t++)
+                    if (dist[t] > dist[t + step]) {
+                        lab[t] = lab[t + step];
+                        dist[t] = dist[t + step];
+                    }
+            ld[p].l = lab[0];
+            ld[p].d = dist[0];
+            labels[p] = lab[0];
+            if (z < 50.0f && depth_sigma != 0.0f) { /* .cu:308-312 */
+                ld[p].l = -1;
+                ld[p].d = 0.0f;
+                labels[p] = -1;
+            }
+        }
+    }
+}
+
+/* analyzeClusters<256> — .cu:315-568 */
+void okde_dasp_analyze_clusters(int width, int height, int rows, int cols, const uint8_t* bgr,
+                                const okde_float3* points, const okde_label_distance* ld,
+                                okde_superpixel* mean, okde_float3* centers, const float* intr)
+{
+    const int wx = width / cols, wy = height / rows;
+    const int rpx = wx * 2 / 16 + 1, rpy = wy * 2 / 16 + 1;
+    for (int cy = 0; cy < rows; cy++) {
+        for (int cx = 0; cx < cols; cx++) {
+            const int cluster_id = cy * cols + cx;
+            int rs[256], gs[256], bs[256], xs[256], ys[256], sz[256], np[256];
+            float xw[256], yw[256], zw[256];
+            const int mx = mean[cluster_id].x, my = mean[cluster_id].y;
+            for (int ty = 0; ty < 16; ty++) {
+                for (int tx = 0; tx < 16; tx++) {
+                    const int tid = ty * 16 + tx;
+                    int r_ = 0, g_ = 0, b_ = 0, x_ = 0, y_ = 0, s_ = 0, n_ = 0;
+                    float xf = 0.0f, yf = 0.0f, zf = 0.0f;
+                    for (int yy = 0; yy < rpy; yy++) {
+                        for (int xx = 0; xx < rpx; xx++) {
+                            const int arx = mx + (tx - 8) * rpx + xx;
+                            const int ary = my + (ty - 8) * rpy + yy;
+                            if (arx >= 0 && arx < width && ary >= 0 && ary < height) {
+                                const size_t q = (size_t)ary * width + arx;
+                                if (ld[q].l == cluster_id) {
+                                    r_ += (int)bgr[q * 3];
+                                    g_ += (int)bgr[q * 3 + 1];
+                                    b_ += (int)bgr[q * 3 + 2];
+                                    x_ += arx;
+                                    y_ += ary;
+                                    s_ += 1;
+                                    xf += points[q].x;
+                                    yf += points[q].y;
+                                    zf += points[q].z;
+                                    n_ += points[q].z > 50.0f ? 1 : 0;
+                                }
+                            }
+                        }
+                    }
+                    rs[tid] = r_; gs[tid] = g_; bs[tid] = b_; xs[tid] = x_; ys[tid] = y_;
+                    sz[tid] = s_; np[tid] = n_; xw[tid] = xf; yw[tid] = yf; zw[tid] = zf;
+                }
+            }
+            /* 256-way tree sum (.cu:425-528); element 0 is what tid 0 stores */
+            for (int step = 128; step >= 1; step >>= 1)
+                for (int t = 0; t < step; t++) {
+                    rs[t] += rs[t + step]; gs[t] += gs[t + step]; bs[t] += bs[t + step];
+                    xs[t] += xs[t + step]; ys[t] += ys[t + step];
+                    xw[t] += xw[t + step]; yw[t] += yw[t + step]; zw[t] += zw[t + step];
+                    sz[t] += sz[t + step]; np[t] += np[t + step];
+                }
+            if (sz[0] != 0) { /* .cu:530-566 */
+                int r = rs[0] / sz[0] > 255 ? 255 : rs[0] / sz[0];
+                int g = gs[0] / sz[0] > 255 ? 255 : gs[0] / sz[0];
+                int b = bs[0] / sz[0] > 255 ? 255 : bs[0] / sz[0];
+                r = r < 0 ? 0 : r; g = g < 0 ? 0 : g; b = b < 0 ? 0 : b;
+                int pix_x, pix_y;
+                if (np[0] != 0) {
+                    centers[cluster_id].x = xw[0] / (float)np[0];
+                    centers[cluster_id].y = yw[0] / (float)np[0];
+                    centers[cluster_id].z = zw[0] / (float)np[0];
+                    float nx = centers[cluster_id].x / centers[cluster_id].z;
+                    float ny = centers[cluster_id].y / centers[cluster_id].z;
+                    pix_x = f2i_rz(nx * intr[0] + intr[2]);
+                    pix_y = f2i_rz(intr[5] - ny * intr[4]);
+                    /* sic: 'pixel.y<=height' (.cu:549) discards every in-image projection */
+                    if (pix_x < 0 || pix_x >= width || pix_y < 0 || pix_y <= height) {
+                        pix_x = xs[0] / sz[0];
+                        pix_y = ys[0] / sz[0];
+                    }
+                } else {
+                    pix_x = xs[0] / sz[0];
+                    pix_y = ys[0] / sz[0];
+                }
+                mean[cluster_id].x = pix_x;
+                mean[cluster_id].y = pix_y;
+                mean[cluster_id].r = (uint8_t)r;
+                mean[cluster_id].g = (uint8_t)g;
+                mean[cluster_id].b = (uint8_t)b;
+                mean[cluster_id].size = sz[0];
+            }
+        }
+    }
+}
+
+/* DepthAdaptiveSuperpixel::Segmentation — .cu:570-588 */
+int okde_dasp_segmentation(int width, int height, int rows, int cols, const float* intr9,
+                           const uint8_t* bgr, const okde_float3* points,
+                           float color_sigma, float spatial_sigma, float depth_sigma, int iteration,
+                           int32_t* labels, okde_label_distance* ld,
+                           okde_superpixel* mean, okde_float3* centers)
+{
+    if (okde_dasp_check_geometry(width, height, rows, cols)) return 1;
+    okde_dasp_init_ld(width, height, rows, cols, ld);
+    okde_dasp_sample_clusters(width, height, rows, cols, bgr, points, mean, centers);
+    for (int i = 0; i < iteration; i++) {
+        okde_dasp_calculate_ld(width, height, rows, cols, bgr, points, ld, mean, centers, labels,
+                               color_sigma, spatial_sigma, depth_sigma);
+        okde_dasp_analyze_clusters(width, height, rows, cols, bgr, points, ld, mean, centers, intr9);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K9 — edge_refining, EdgeRefinedSuperpixel/EdgeRefinedSuperpixel.cu:4-102, with snapshot
+ * semantics (D2): in each phase every source pixel evaluates its rule on the phase-start
+ * labels/depth (its depth-zeroing cascade sees only its own writes); write-sets are applied in
+ * raster order of the source pixel (later source wins for labels; depth writes only ever store 0).
+ * dir = 0: horizontal scan (.cu:15-57); dir = 1: vertical scan (.cu:59-101).
+ * ---------------------------------------------------------------------------------------- */
+static void edge_phase(int width, int height, const int32_t* color_labels,
+                       const int32_t* L0, const float* D0, int32_t* L1, float* D1,
+                       int window_size, int dir)
+{
+    const int len = dir == 0 ? width : height;        /* extent along the scan direction   */
+    const size_t stride = dir == 0 ? 1 : (size_t)width;
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            const int pos = dir == 0 ? x : y;         /* coordinate along the scan          */
+            const size_t base = (size_t)y * width + x - (size_t)pos * stride; /* pos == 0 cell */
+#define AT(arr, k) ((arr)[base + (size_t)(k) * stride])
+            if (!(pos + 1 < len)) continue;
+            if (AT(L0, pos) == AT(L0, pos + 1)) continue;
+            const int current_color_label = AT(color_labels, pos);
+            int target_color_label = current_color_label;
+            int distance = 0;
+            while ((pos - distance >= 0 || pos + distance < len) &&
+                   target_color_label == current_color_label && distance <= window_size / 2) {
+                int tp = pos - distance;
+                if (tp >= 0) target_color_label = AT(color_labels, tp);
+                if (target_color_label != current_color_label) {
+                    const int refined_depth_label = AT(L0, pos + 1);
+                    for (int i = tp + 1; i <= pos; i++) {
+                        AT(L1, i) = refined_depth_label;
+                        /* reads i and i+1: i+1 is never written earlier by this source */
+                        if (fabsf(AT(D0, i) - AT(D0, i + 1)) > AT(D0, i) * 0.1f) AT(D1, i) = 0.0f;
+                    }
+                    break;
+                }
+                tp = pos + distance;
+                if (tp < len) target_color_label = AT(color_labels, tp);
+                if (target_color_label != current_color_label) {
+                    const int refined_depth_label = AT(L0, pos);
+                    float prev = AT(D0, pos);           /* own-write overlay for the cascade */
+                    for (int i = pos + 1; i <= tp - 1; i++) {
+                        AT(L1, i) = refined_depth_label;
+                        float cur = AT(D0, i);
+                        if (fabsf(cur - prev) > cur * 0.1f) {
+                            AT(D1, i) = 0.0f;
+                            cur = 0.0f;
+                        }
+                        prev = cur;
+                    }
+                    break;
+                }
+                distance++;
+            }
+#undef AT
+        }
+    }
+}
+
+void okde_ers_edge_refining(int width, int height, const int32_t* color_labels,
+                            int32_t* refined_labels, float* refined_depth, int window)
+{
+    const size_t n = (size_t)width * height;
+    int32_t* L0 = (int32_t*)malloc(n * sizeof(int32_t));
+    float* D0 = (float*)malloc(n * sizeof(float));
+    for (int dir = 0; dir < 2; dir++) {
+        memcpy(L0, refined_labels, n * sizeof(int32_t));
+        memcpy(D0, refined_depth, n * sizeof(float));
+        edge_phase(width, height, color_labels, L0, D0, refined_labels, refined_depth, window, dir);
+    }
+    free(L0);
+    free(D0);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K10 — depthmap_enhancement, EdgeRefinedSuperpixel.cu:104-205 (D3: separate output buffer)
+ * ---------------------------------------------------------------------------------------- */
+void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr,
+                      const int32_t* refined_labels, const float* spatial, int window_size,
+                      float color_sigma_in, float depth_sigma, float* out)
+{
+    const int hw = window_size / 2;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            const size_t p = (size_t)y * width + x;
+            const uint8_t* cc = bgr + p * 3;
+            float color_sigma = color_sigma_in; /* by-value kernel argument, mutated below */
+            float w_average = 0.0f, weight = 0.0f;
+            for (int i = -hw; i <= hw; i++)
+                for (int j = -hw; j <= hw; j++) {
+                    int xj = x + j, yi = y + i;
+                    if (xj >= 0 && xj < width && yi >= 0 && yi < height) {
+                        const size_t q = (size_t)yi * width + xj;
+                        if (rd[q] > 50.0f && refined_labels[p] == refined_labels[q]) {
+                            float color_diff = color_diff3(cc, bgr + q * 3);
+                            float color_filter = 0.0f;
+                            if (color_sigma != 0.0f)
+                                color_filter = expf(-color_diff / (2 * (color_sigma * color_sigma)));
+                            float filter = 1.0f;
+                            float s = spatial[(i + hw) * window_size + (j + hw)];
+                            if (s != 0.0f) filter *= s;
+                            if (color_filter != 0.0f) filter *= color_filter;
+                            w_average += rd[q] * filter;
+                            weight += filter;
+                        }
+                    }
+                }
+            float result = 0.0f;
+            if (weight > 0.0f) {
+                w_average /= weight;
+                /* deviation — .cu:143-156 */
+                int count = 0;
+                float deviation = 0.0f;
+                for (int i = -hw; i <= hw; i++)
+                    for (int j = -hw; j <= hw; j++) {
+                        int xj = x + j, yi = y + i;
+                        if (xj >= 0 && xj < width && yi >= 0 && yi < height) {
+                            const size_t q = (size_t)yi * width + xj;
+                            if (rd[q] > 50.0f && refined_labels[p] == refined_labels[q]) {
+                                deviation += fabsf(rd[q] - w_average);
+                                count++;
+                            }
+                        }
+                    }
+                if (count != 0) deviation /= (float)count;
+                /* filtering — .cu:158-200; the label test is commented out in the reference */
+                float numerator = 0.0f, denominator = 0.0f;
+                for (int i = -hw; i <= hw; i++)
+                    for (int j = -hw; j <= hw; j++) {
+                        int xj = x + j, yi = y + i;
+                        if (xj >= 0 && xj < width && yi >= 0 && yi < height) {
+                            const size_t q = (size_t)yi * width + xj;
+                            if (rd[q] > 50.0f) {
+                                float color_diff = color_diff3(cc, bgr + q * 3);
+                                float color_filter = 0.0f;
+                                if (color_sigma != 0.0f) {
+                                    /* .cu:171: 5.0 is a double literal; pow(float,float) is float */
+                                    float adaptive_sigma =
+                                        (float)(5.0 * (double)deviation / (double)(w_average * w_average));
+                                    if (adaptive_sigma > color_sigma * 0.3f) color_sigma = adaptive_sigma;
+                                    else color_sigma *= 0.3f;
+                                    color_filter = expf(-color_diff / (2 * (color_sigma * color_sigma)));
+                                }
+                                float dd = rd[q] - w_average;
+                                float depth_diff = dd * dd;
+                                float depth_filter = 0.0f; /* Q3 */
+                                if (depth_sigma != 0.0f)
+                                    depth_filter = expf(-depth_diff / (2.0f * (depth_sigma * depth_sigma)));
+                                float filter = 1.0f;
+                                float s = spatial[(i + hw) * window_size + (j + hw)];
+                                if (s != 0.0f) filter *= s;
+                                if (color_filter != 0.0f) filter *= color_filter;
+                                if (depth_filter != 0.0f) filter *= depth_filter;
+                                numerator += rd[q] * filter;
+                                denominator += filter;
+                            }
+                        }
+                    }
+                if (denominator == 0.0f) result = 0.0f;
+                else result = numerator / denominator;
+            }
+            out[p] = result;
+        }
+    }
+}
+
+/* EdgeRefinedSuperpixel::EdgeRefining — .cu:208-223; constants EdgeRefinedSuperpixel.cpp:4-7 */
+void okde_ers_process(int width, int height, const int32_t* color_labels, const int32_t* depth_labels,
+                      const float* depth, const uint8_t* bgr,
+                      int32_t* refined_labels, float* refined_depth)
+{
+    const size_t n = (size_t)width * height;
+    const int WindowSize = 7;
+    const float SpatialSigma = 30.0f, ColorSigma = 50.0f, DepthSigma = 70.0f;
+    float table[49];
+    okde_spatial_table(WindowSize, SpatialSigma, table);
+    memcpy(refined_labels, depth_labels, n * sizeof(int32_t));
+    float* tmp = (float*)malloc(n * sizeof(float));
+    memcpy(tmp, depth, n * sizeof(float));
+    okde_ers_edge_refining(width, height, color_labels, refined_labels, tmp, WindowSize);
+    okde_ers_enhance(width, height, tmp, bgr, refined_labels, table, WindowSize, ColorSigma, DepthSigma,
+                     refined_depth);
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * RegionGrowingBilateralFilter::Process — RegionGrowingBilateralFilter.cpp:27-38
+ * ---------------------------------------------------------------------------------------- */
+static int two_segmentations_then_ers(int width, int height, int rows, int cols, const float* intr9,
+                                      const float* depth, const okde_float3* points, const uint8_t* bgr,
+                                      float c1, float s1, float d1, float c2, float s2, float d2, int iters,
+                                      int32_t* sp_labels, int32_t* dasp_labels,
+                                      int32_t* refined_labels, float* refined_depth)
+{
+    const size_t n = (size_t)width * height;
+    const int k = rows * cols;
+    if (okde_dasp_check_geometry(width, height, rows, cols)) return 1;
+    okde_label_distance* ld = (okde_label_distance*)malloc(n * sizeof(*ld));
+    okde_superpixel* mean = (okde_superpixel*)calloc((size_t)k, sizeof(*mean));
+    okde_float3* centers = (okde_float3*)calloc((size_t)k, sizeof(*centers));
+    int32_t* l1 = sp_labels ? sp_labels : (int32_t*)malloc(n * sizeof(int32_t));
+    int32_t* l2 = dasp_labels ? dasp_labels : (int32_t*)malloc(n * sizeof(int32_t));
+    okde_dasp_segmentation(width, height, rows, cols, intr9, bgr, points, c1, s1, d1, iters, l1, ld, mean, centers);
+    memset(mean, 0, (size_t)k * sizeof(*mean));
+    memset(centers, 0, (size_t)k * sizeof(*centers));
+    okde_dasp_segmentation(width, height, rows, cols, intr9, bgr, points, c2, s2, d2, iters, l2, ld, mean, centers);
+    okde_ers_process(width, height, l1, l2, depth, bgr, refined_labels, refined_depth);
+    if (!sp_labels) free(l1);
+    if (!dasp_labels) free(l2);
+    free(ld); free(mean); free(centers);
+    return 0;
+}
+
+int okde_rgbf_process(int width, int height, int rows, int cols, const float* intr9,
+                      const float* depth, const okde_float3* points, const uint8_t* bgr,
+                      int32_t* sp_labels, int32_t* dasp_labels,
+                      int32_t* refined_labels, float* refined_depth)
+{
+    /* SP(200,40,0,1), DASP(100,20,200,1) — RegionGrowingBilateralFilter.cpp:28-29 */
+    return two_segmentations_then_ers(width, height, rows, cols, intr9, depth, points, bgr,
+                                      200.0f, 40.0f, 0.0f, 100.0f, 20.0f, 200.0f, 1,
+                                      sp_labels, dasp_labels, refined_labels, refined_depth);
+}
+
+int okde_spdsr_head(int width, int height, int rows, int cols, const double* K9,
+                    const float* depth, const okde_float3* points, const uint8_t* bgr,
+                    int32_t* refined_labels, float* refined_depth, okde_float3* refined_points)
+{
+    float intr9[9];
+    for (int i = 0; i < 9; i++) intr9[i] = (float)K9[i]; /* DepthAdaptiveSuperpixel.cpp:33-37 */
+    /* SP(200,10,0,5), DASP(0,10,200,5) — SPDepthSuperResolution.cpp:59-64 */
+    int rc = two_segmentations_then_ers(width, height, rows, cols, intr9, depth, points, bgr,
+                                        200.0f, 10.0f, 0.0f, 0.0f, 10.0f, 200.0f, 5,
+                                        NULL, NULL, refined_labels, refined_depth);
+    if (rc) return rc;
+    /* Convertor->setCameraParameters(intrinsic, ...) — DimensionConvertor.cpp:3-13 */
+    okde_p2r_depth(width, height, (float)K9[0], (float)K9[4], (int)K9[2], (int)K9[5], refined_depth, refined_points);
+    return 0;
+}
+
+/* main.cpp:220-308 */
+double okde_mean_3d_error(int n, const okde_float3* pts, const okde_float3* truth, int* count_out)
+{
+    float acc = 0.0f;
+    int count = 0;
+    for (int i = 0; i < n; i++) {
+        if (pts[i].z > 50.0f && pts[i].z < 15000.0f && truth[i].z > 50.0f && truth[i].z < 15000.0f) {
+            float dz = pts[i].z - truth[i].z, dy = pts[i].y - truth[i].y, dx = pts[i].x - truth[i].x;
+            acc += sqrtf(dz * dz + dy * dy + dx * dx);
+            count++;
+        }
+    }
+    if (count_out) *count_out = count;
+    return (double)(acc / (float)count);
+}

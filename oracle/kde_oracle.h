@@ -1,0 +1,133 @@
+/*
+ * oracle/kde_oracle.h — CPU restatement of the reference's depth-enhancement hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is product code: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and only as the
+ * checker / reported CPU baseline.  The shipped path (kinectdepthmapenhancement_amd/csrc)
+ * never links, includes or calls anything here.
+ *
+ * PARITY UNPINNED: the reference (stevesuyao/KinectDepthMapEnhancement) has no tests,
+ * golden vectors or known-answer data for this path, its only input fixture
+ * (input/depth.xml) is absent, and it cannot be built here (nvcc / OpenCV 2.4.3 gpu /
+ * OpenNI / PCL missing).  This file is a line-by-line scalar restatement of the CUDA
+ * kernels, reviewed against the cited file:line ranges, with the documented deviations
+ * D1-D4 where the reference is racy or reads out of bounds.
+ *
+ * All arithmetic is IEEE float32, compiled with -O2 -ffp-contract=off, libm expf/sqrtf,
+ * denormals on.  powf(x,2)/pow(x,2) of the reference are written x*x (Q9).
+ */
+#ifndef KDE_ORACLE_H
+#define KDE_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y, z; } okde_float3;            /* CUDA float3, 12 B packed       */
+typedef struct { float d, w; } okde_weighted_d;           /* ArrayBuffer/ArrayBuffer.h:12-15 */
+typedef struct {                                          /* SuperpixelSegmentation.h:17-24  */
+    uint8_t r, g, b, pad_;
+    int32_t x, y, size;
+} okde_superpixel;                                        /* 16 B                            */
+typedef struct { float d; int32_t l; } okde_label_distance; /* SuperpixelSegmentation.h:26-29 */
+
+/* threads used by the OpenMP legs of the heavy functions (1 = serial). Returns previous. */
+int okde_set_threads(int n);
+int okde_max_threads(void);
+
+/* JointBilateralFilter/JointBilateralFilter.cpp:31-40 (also EdgeRefinedSuperpixel.cpp:46-55) */
+void okde_spatial_table(int window, float sigma, float* table /* window*window */);
+
+/* K0: cv::gpu::bilateralFilter (OpenCV 2.4.3 gpu module, call site
+ * JointBilateralFilter/JointBilateralFilter.cu:285) on a packed 8UC3 image. */
+void okde_cv_bilateral_8uc3(const uint8_t* src, int width, int height, size_t src_step,
+                            int kernel_size, float sigma_color, float sigma_spatial,
+                            uint8_t* dst, size_t dst_step);
+
+/* K1: joint_bilateral_filtering, JointBilateralFilter/JointBilateralFilter.cu:4-83.
+ * ill (optional, may be NULL): per-pixel flag set when the final denominator is positive but
+ * < 1e-30 (every surviving weight is a denormal-scale number: result is ill-conditioned). */
+void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* guide_bgr,
+                     const float* spatial, int window, float color_sigma, float depth_sigma,
+                     float* filtered, uint8_t* ill);
+
+/* JointBilateralFilter::Process, JointBilateralFilter.cu:283-290 (K0 then K1).
+ * presmooth_ksize <= -1000 disables the pre-smoothing (guide = colour). */
+void okde_jbf_process(int width, int height, const float* depth, const uint8_t* bgr,
+                      int window, float spatial_sigma, float color_sigma, float depth_sigma,
+                      int presmooth_ksize, float presmooth_sigma_color, float presmooth_sigma_spatial,
+                      uint8_t* smooth_out /* W*H*3 */, float* filtered, uint8_t* ill);
+
+/* MarkovRandomField/MarkovRandomField.cu:4-40 (next-row f1) */
+void okde_mrf_kernel(int width, int height, const float* depth, const uint8_t* bgr,
+                     int window, float color_sigma, float smooth_sigma, float* filtered);
+
+/* DimensionConvertor: .cpp:3-13 truncates cx, cy to int; functors .h:19-148; calls .cu:3-77 */
+void okde_p2r_depth(int width, int height, float fx, float fy, int cx, int cy,
+                    const float* depth, okde_float3* out);
+void okde_p2r_points(int width, int height, float fx, float fy, int cx, int cy,
+                     const okde_float3* in, okde_float3* out);
+void okde_p2r_interp(int width, int height, float fx, float fy, int cx, int cy,
+                     const float* depth, okde_float3* out);
+void okde_r2p(int width, int height, float fx, float fy, int cx, int cy,
+              const okde_float3* in, okde_float3* out);
+
+/* Buffer2D: ArrayBuffer/ArrayBuffer.cu:9-22, Buffer2D.cu:13-147, Buffer2D.cpp:13-15 */
+void okde_buf_init(int n, okde_weighted_d* buf);
+void okde_buf_insert_depth(int n, okde_weighted_d* buf, const float* data);
+void okde_buf_insert_float2(int width, int height, okde_weighted_d* buf, const float* data_xy);
+void okde_buf_get_depth(int n, const okde_weighted_d* buf, float* out);
+void okde_buf_get_weight(int n, const okde_weighted_d* buf, float* out);
+void okde_buf_update(int n, okde_weighted_d* buf, const float* data);
+
+/* DepthAdaptiveSuperpixel (K5-K8), SuperpixelSegmentation/DepthAdaptiveSuperpixel.cu:3-588.
+ * Returns 0, or 1 if the geometry is rejected (see DESIGN.md "DASP geometry guard"). */
+int okde_dasp_check_geometry(int width, int height, int rows, int cols);
+void okde_dasp_init_ld(int width, int height, int rows, int cols, okde_label_distance* ld);
+void okde_dasp_sample_clusters(int width, int height, int rows, int cols, const uint8_t* bgr,
+                               const okde_float3* points, okde_superpixel* mean, okde_float3* centers);
+void okde_dasp_calculate_ld(int width, int height, int rows, int cols, const uint8_t* bgr,
+                            const okde_float3* points, okde_label_distance* ld,
+                            const okde_superpixel* mean, const okde_float3* centers, int32_t* labels,
+                            float color_sigma, float spatial_sigma, float depth_sigma);
+void okde_dasp_analyze_clusters(int width, int height, int rows, int cols, const uint8_t* bgr,
+                                const okde_float3* points, const okde_label_distance* ld,
+                                okde_superpixel* mean, okde_float3* centers, const float* intr9);
+int okde_dasp_segmentation(int width, int height, int rows, int cols, const float* intr9,
+                           const uint8_t* bgr, const okde_float3* points,
+                           float color_sigma, float spatial_sigma, float depth_sigma, int iteration,
+                           int32_t* labels, okde_label_distance* ld,
+                           okde_superpixel* mean, okde_float3* centers);
+
+/* EdgeRefinedSuperpixel (K9, K10), EdgeRefinedSuperpixel/EdgeRefinedSuperpixel.cu:4-223 */
+void okde_ers_edge_refining(int width, int height, const int32_t* color_labels,
+                            int32_t* refined_labels /* in/out */, float* refined_depth /* in/out */,
+                            int window);
+void okde_ers_enhance(int width, int height, const float* refined_depth_in, const uint8_t* bgr,
+                      const int32_t* refined_labels, const float* spatial, int window,
+                      float color_sigma, float depth_sigma, float* refined_depth_out);
+void okde_ers_process(int width, int height, const int32_t* color_labels, const int32_t* depth_labels,
+                      const float* depth, const uint8_t* bgr,
+                      int32_t* refined_labels, float* refined_depth);
+
+/* RegionGrowingBilateralFilter::Process, RegionGrowingBilateralFilter.cpp:27-38 */
+int okde_rgbf_process(int width, int height, int rows, int cols, const float* intr9,
+                      const float* depth, const okde_float3* points, const uint8_t* bgr,
+                      int32_t* sp_labels, int32_t* dasp_labels,
+                      int32_t* refined_labels, float* refined_depth);
+
+/* SPDepthSuperResolution::Process head, SPDepthSuperResolution.cpp:57-64
+ * (DASPx2 with 5 iterations -> ERS -> projectiveToReal).  The PCA / projection tail is f2. */
+int okde_spdsr_head(int width, int height, int rows, int cols, const double* K9,
+                    const float* depth, const okde_float3* points, const uint8_t* bgr,
+                    int32_t* refined_labels, float* refined_depth, okde_float3* refined_points);
+
+/* main.cpp:220-308 — mean Euclidean 3-D error (mm) over pixels valid (50<z<15000) in both */
+double okde_mean_3d_error(int n, const okde_float3* pts, const okde_float3* truth, int* count_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,319 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/kde_oracle.c).
+
+TEST INFRASTRUCTURE ONLY — PARITY UNPINNED (see kde_oracle.h).  Imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libkde_oracle.so")
+
+FLOAT3 = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
+WEIGHTED_D = np.dtype([("d", "<f4"), ("w", "<f4")])
+SUPERPIXEL = np.dtype([("r", "u1"), ("g", "u1"), ("b", "u1"), ("pad", "u1"),
+                       ("x", "<i4"), ("y", "<i4"), ("size", "<i4")])
+LABEL_DISTANCE = np.dtype([("d", "<f4"), ("l", "<i4")])
+assert FLOAT3.itemsize == 12 and SUPERPIXEL.itemsize == 16 and LABEL_DISTANCE.itemsize == 8
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "kde_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.okde_mean_3d_error.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def set_threads(n: int) -> int:
+    return lib().okde_set_threads(int(n))
+
+
+def max_threads() -> int:
+    return lib().okde_max_threads()
+
+
+def spatial_table(window: int, sigma: float) -> np.ndarray:
+    t = np.empty((window, window), np.float32)
+    lib().okde_spatial_table(window, C.c_float(sigma), _p(t))
+    return t
+
+
+def cv_bilateral(bgr: np.ndarray, ksize: int = 5, sigma_color: float = 30.0,
+                 sigma_spatial: float = 30.0) -> np.ndarray:
+    bgr = _u8(bgr)
+    h, w, _ = bgr.shape
+    out = np.empty_like(bgr)
+    lib().okde_cv_bilateral_8uc3(_p(bgr), w, h, C.c_size_t(w * 3), ksize, C.c_float(sigma_color),
+                                 C.c_float(sigma_spatial), _p(out), C.c_size_t(w * 3))
+    return out
+
+
+def jbf_kernel(depth, guide, window=5, spatial_sigma=70.0, color_sigma=50.0, depth_sigma=20.0,
+               return_ill=False):
+    depth, guide = _f32(depth), _u8(guide)
+    h, w = depth.shape
+    tab = spatial_table(window, spatial_sigma)
+    out = np.empty((h, w), np.float32)
+    ill = np.zeros((h, w), np.uint8)
+    lib().okde_jbf_kernel(w, h, _p(depth), _p(guide), _p(tab), window, C.c_float(color_sigma),
+                          C.c_float(depth_sigma), _p(out), _p(ill))
+    return (out, ill) if return_ill else out
+
+
+def jbf_process(depth, bgr, window=5, spatial_sigma=70.0, color_sigma=50.0, depth_sigma=20.0,
+                presmooth=(5, 30.0, 30.0), return_all=False):
+    """JointBilateralFilter::Process. presmooth=None disables K0."""
+    depth, bgr = _f32(depth), _u8(bgr)
+    h, w = depth.shape
+    out = np.empty((h, w), np.float32)
+    smooth = np.empty((h, w, 3), np.uint8)
+    ill = np.zeros((h, w), np.uint8)
+    ks, sc, ss = presmooth if presmooth is not None else (-100000, 0.0, 0.0)
+    lib().okde_jbf_process(w, h, _p(depth), _p(bgr), window, C.c_float(spatial_sigma),
+                           C.c_float(color_sigma), C.c_float(depth_sigma), ks, C.c_float(sc),
+                           C.c_float(ss), _p(smooth), _p(out), _p(ill))
+    return (out, smooth, ill) if return_all else out
+
+
+def mrf_kernel(depth, bgr, window=5, color_sigma=50.0, smooth_sigma=150.0):
+    depth, bgr = _f32(depth), _u8(bgr)
+    h, w = depth.shape
+    out = np.empty((h, w), np.float32)
+    lib().okde_mrf_kernel(w, h, _p(depth), _p(bgr), window, C.c_float(color_sigma),
+                          C.c_float(smooth_sigma), _p(out))
+    return out
+
+
+def camera_from_K(K):
+    """DimensionConvertor::setCameraParameters (DimensionConvertor.cpp:3-13)."""
+    K = np.asarray(K, np.float64).reshape(3, 3)
+    return float(np.float32(K[0, 0])), float(np.float32(K[1, 1])), int(K[0, 2]), int(K[1, 2])
+
+
+def p2r_depth(depth, K):
+    depth = _f32(depth)
+    h, w = depth.shape
+    fx, fy, cx, cy = camera_from_K(K)
+    out = np.empty((h, w), FLOAT3)
+    lib().okde_p2r_depth(w, h, C.c_float(fx), C.c_float(fy), cx, cy, _p(depth), _p(out))
+    return out
+
+
+def _pts(points):
+    a = np.ascontiguousarray(points)
+    if a.dtype != FLOAT3:
+        a = np.ascontiguousarray(a, np.float32)
+        assert a.shape[-1] == 3
+        a = a.view(FLOAT3).reshape(a.shape[:-1])
+    return a
+
+
+def p2r_points(points, K):
+    pts = _pts(points)
+    h, w = pts.shape
+    fx, fy, cx, cy = camera_from_K(K)
+    out = np.empty((h, w), FLOAT3)
+    lib().okde_p2r_points(w, h, C.c_float(fx), C.c_float(fy), cx, cy, _p(pts), _p(out))
+    return out
+
+
+def p2r_interp(depth, K):
+    depth = _f32(depth)
+    h, w = depth.shape
+    fx, fy, cx, cy = camera_from_K(K)
+    out = np.empty((h, w), FLOAT3)
+    lib().okde_p2r_interp(w, h, C.c_float(fx), C.c_float(fy), cx, cy, _p(depth), _p(out))
+    return out
+
+
+def r2p(points, K):
+    pts = _pts(points)
+    h, w = pts.shape
+    fx, fy, cx, cy = camera_from_K(K)
+    out = np.empty((h, w), FLOAT3)
+    lib().okde_r2p(w, h, C.c_float(fx), C.c_float(fy), cx, cy, _p(pts), _p(out))
+    return out
+
+
+class Buffer2D:
+    """Mirror of ArrayBuffer/Buffer2D on the CPU."""
+
+    def __init__(self, width, height):
+        self.w, self.h = width, height
+        self.buf = np.empty((height, width), WEIGHTED_D)
+        lib().okde_buf_init(width * height, _p(self.buf))
+
+    def insert_depth(self, data):
+        lib().okde_buf_insert_depth(self.w * self.h, _p(self.buf), _p(_f32(data)))
+
+    def insert_float2(self, data_xy):
+        d = _f32(data_xy)
+        assert d.shape == (self.h, self.w, 2)
+        lib().okde_buf_insert_float2(self.w, self.h, _p(self.buf), _p(d))
+
+    def insert_weighted(self, other):
+        self.buf[...] = np.asarray(other).view(WEIGHTED_D).reshape(self.h, self.w)
+
+    def update(self, data):
+        lib().okde_buf_update(self.w * self.h, _p(self.buf), _p(_f32(data)))
+
+    def depth_map(self):
+        out = np.empty((self.h, self.w), np.float32)
+        lib().okde_buf_get_depth(self.w * self.h, _p(self.buf), _p(out))
+        return out
+
+    def weight_map(self):
+        out = np.empty((self.h, self.w), np.float32)
+        lib().okde_buf_get_weight(self.w * self.h, _p(self.buf), _p(out))
+        return out
+
+
+def intr9(K):
+    return np.ascontiguousarray(np.asarray(K, np.float64).reshape(9).astype(np.float32))
+
+
+def dasp_segmentation(bgr, points, rows, cols, K, color_sigma, spatial_sigma, depth_sigma, iteration):
+    bgr, pts = _u8(bgr), _pts(points)
+    h, w = pts.shape
+    labels = np.empty((h, w), np.int32)
+    ld = np.empty((h, w), LABEL_DISTANCE)
+    mean = np.zeros(rows * cols, SUPERPIXEL)
+    centers = np.zeros(rows * cols, FLOAT3)
+    k = intr9(K)
+    rc = lib().okde_dasp_segmentation(w, h, rows, cols, _p(k), _p(bgr), _p(pts),
+                                      C.c_float(color_sigma), C.c_float(spatial_sigma),
+                                      C.c_float(depth_sigma), iteration,
+                                      _p(labels), _p(ld), _p(mean), _p(centers))
+    if rc:
+        raise ValueError("DASP geometry rejected")
+    return labels, ld, mean, centers
+
+
+def dasp_steps(bgr, points, rows, cols):
+    """init_LD + sampleInitialClusters only (for unit tests of the individual kernels)."""
+    bgr, pts = _u8(bgr), _pts(points)
+    h, w = pts.shape
+    ld = np.empty((h, w), LABEL_DISTANCE)
+    mean = np.zeros(rows * cols, SUPERPIXEL)
+    centers = np.zeros(rows * cols, FLOAT3)
+    lib().okde_dasp_init_ld(w, h, rows, cols, _p(ld))
+    lib().okde_dasp_sample_clusters(w, h, rows, cols, _p(bgr), _p(pts), _p(mean), _p(centers))
+    return ld, mean, centers
+
+
+def dasp_calculate_ld(bgr, points, rows, cols, ld, mean, centers, color_sigma, spatial_sigma, depth_sigma):
+    bgr, pts = _u8(bgr), _pts(points)
+    h, w = pts.shape
+    ld = np.ascontiguousarray(ld).copy()
+    labels = np.empty((h, w), np.int32)
+    lib().okde_dasp_calculate_ld(w, h, rows, cols, _p(bgr), _p(pts), _p(ld), _p(np.ascontiguousarray(mean)),
+                                 _p(np.ascontiguousarray(centers)), _p(labels), C.c_float(color_sigma),
+                                 C.c_float(spatial_sigma), C.c_float(depth_sigma))
+    return labels, ld
+
+
+def dasp_analyze_clusters(bgr, points, rows, cols, ld, mean, centers, K):
+    bgr, pts = _u8(bgr), _pts(points)
+    h, w = pts.shape
+    mean = np.ascontiguousarray(mean).copy()
+    centers = np.ascontiguousarray(centers).copy()
+    k = intr9(K)
+    lib().okde_dasp_analyze_clusters(w, h, rows, cols, _p(bgr), _p(pts), _p(np.ascontiguousarray(ld)),
+                                     _p(mean), _p(centers), _p(k))
+    return mean, centers
+
+
+def ers_edge_refining(color_labels, depth_labels, depth, window=7):
+    cl, labels, d = _i32(color_labels), _i32(depth_labels).copy(), _f32(depth).copy()
+    h, w = d.shape
+    lib().okde_ers_edge_refining(w, h, _p(cl), _p(labels), _p(d), window)
+    return labels, d
+
+
+def ers_enhance(refined_depth, bgr, refined_labels, window=7, spatial_sigma=30.0, color_sigma=50.0,
+                depth_sigma=70.0):
+    rd, bgr, rl = _f32(refined_depth), _u8(bgr), _i32(refined_labels)
+    h, w = rd.shape
+    tab = spatial_table(window, spatial_sigma)
+    out = np.empty((h, w), np.float32)
+    lib().okde_ers_enhance(w, h, _p(rd), _p(bgr), _p(rl), _p(tab), window, C.c_float(color_sigma),
+                           C.c_float(depth_sigma), _p(out))
+    return out
+
+
+def ers_process(color_labels, depth_labels, depth, bgr):
+    cl, dl, d, bgr = _i32(color_labels), _i32(depth_labels), _f32(depth), _u8(bgr)
+    h, w = d.shape
+    rl = np.empty((h, w), np.int32)
+    rd = np.empty((h, w), np.float32)
+    lib().okde_ers_process(w, h, _p(cl), _p(dl), _p(d), _p(bgr), _p(rl), _p(rd))
+    return rl, rd
+
+
+def rgbf_process(depth, points, bgr, rows, cols, K):
+    d, pts, bgr = _f32(depth), _pts(points), _u8(bgr)
+    h, w = d.shape
+    sp = np.empty((h, w), np.int32)
+    da = np.empty((h, w), np.int32)
+    rl = np.empty((h, w), np.int32)
+    rd = np.empty((h, w), np.float32)
+    k = intr9(K)
+    rc = lib().okde_rgbf_process(w, h, rows, cols, _p(k), _p(d), _p(pts), _p(bgr),
+                                 _p(sp), _p(da), _p(rl), _p(rd))
+    if rc:
+        raise ValueError("DASP geometry rejected")
+    return {"sp_labels": sp, "dasp_labels": da, "refined_labels": rl, "refined_depth": rd}
+
+
+def spdsr_head(depth, points, bgr, rows, cols, K):
+    d, pts, bgr = _f32(depth), _pts(points), _u8(bgr)
+    h, w = d.shape
+    rl = np.empty((h, w), np.int32)
+    rd = np.empty((h, w), np.float32)
+    rp = np.empty((h, w), FLOAT3)
+    k = np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))
+    rc = lib().okde_spdsr_head(w, h, rows, cols, _p(k), _p(d), _p(pts), _p(bgr), _p(rl), _p(rd), _p(rp))
+    if rc:
+        raise ValueError("DASP geometry rejected")
+    return rl, rd, rp
+
+
+def mean_3d_error(points, truth):
+    a, b = _pts(points), _pts(truth)
+    cnt = C.c_int(0)
+    e = lib().okde_mean_3d_error(a.size, _p(a), _p(b), C.byref(cnt))
+    return float(e), cnt.value

@@ -1,0 +1,386 @@
+"""Hand-checkable micro-cases and independent pure-Python restatements that pin the CPU oracle.
+
+The reference ships no tests or golden vectors, so the oracle is pinned by
+(a) closed-form cases, (b) slow literal Python ports of the CUDA text written separately from
+oracle/kde_oracle.c, on tiny inputs."""
+import math
+
+import numpy as np
+import pytest
+
+F = np.float32
+
+
+def test_spatial_table_values(oracle):
+    t = oracle.spatial_table(5, 70.0)
+    # JointBilateralFilter.cpp:31-40: exp(-(dx^2+dy^2)/(2*70^2))
+    assert t[2, 2] == 1.0
+    assert abs(t[0, 0] - math.exp(-8 / 9800)) < 1e-7      # corner 0.999184
+    assert abs(t[0, 2] - math.exp(-4 / 9800)) < 1e-7      # edge   0.999592
+    assert np.array_equal(t, t.T) and np.array_equal(t, t[::-1, ::-1])
+    t7 = oracle.spatial_table(7, 30.0)
+    assert abs(t7[0, 0] - math.exp(-18 / 1800)) < 1e-7
+
+
+def _flat(h, w, d=1000.0, c=(10, 20, 30)):
+    depth = np.full((h, w), d, F)
+    bgr = np.empty((h, w, 3), np.uint8)
+    bgr[...] = c
+    return depth, bgr
+
+
+def test_jbf_constant_depth_is_identity(oracle):
+    depth, bgr = _flat(12, 16)
+    out = oracle.jbf_kernel(depth, bgr)
+    assert np.allclose(out, 1000.0, rtol=1e-6)
+
+
+def test_jbf_all_invalid_is_zero(oracle):
+    depth, bgr = _flat(9, 9, d=50.0)    # 50 is NOT valid (strict >)
+    assert np.all(oracle.jbf_kernel(depth, bgr) == 0)
+    depth[...] = 0
+    assert np.all(oracle.jbf_kernel(depth, bgr) == 0)
+
+
+def test_jbf_single_valid_pixel_fills_its_window(oracle):
+    depth, bgr = _flat(11, 11, d=0.0)
+    depth[5, 5] = 1234.5
+    out = oracle.jbf_kernel(depth, bgr)
+    exp = np.zeros_like(depth)
+    exp[3:8, 3:8] = 1234.5          # the centre need not be valid: holes are filled (Q2)
+    assert np.allclose(out, exp, rtol=1e-6)
+
+
+def test_jbf_q1_underflow_discontinuity(oracle):
+    """Q1: a depth factor that underflows to exactly 0 is NOT multiplied in, so an outlier further than
+    sqrt(103.972*2*20^2) = 288.41 mm from the window average regains full weight."""
+    def run(delta):
+        depth, bgr = _flat(5, 5, d=1000.0)
+        depth[2, 4] = 1000.0 + delta
+        return oracle.jbf_kernel(depth, bgr)[2, 2]
+    # 24 taps at 1000 and one at 1000+delta: the average is ~1000+delta/25
+    near = run(250.0)     # |d - avg| = 240 < 288.41 -> weight exp(-72) ~ 0
+    far = run(320.0)      # |d - avg| = 307 > 288.41 -> factor skipped -> weight ~1
+    assert abs(near - 1000.0) < 1e-3
+    inl = 24 * math.exp(-(320.0 / 25) ** 2 / 800)          # the 24 inliers keep their (small) depth factor
+    assert abs(far - (1000.0 + 320.0 / (inl + 1))) < 0.05
+    xT = 150 * math.log(2)
+    assert 288.40 < math.sqrt(xT * 800) < 288.42
+
+
+def test_jbf_sigma_zero_terms_are_skipped(oracle):
+    depth, bgr = _flat(8, 8)
+    depth[3, 3] = 2000.0
+    bgr[3, 3] = (200, 200, 200)
+    a = oracle.jbf_kernel(depth, bgr, 5, 70.0, 0.0, 0.0)     # both terms off: spatial-only average
+    tab = oracle.spatial_table(5, 70.0).astype(np.float64)
+    win = depth[1:6, 1:6].astype(np.float64)
+    assert abs(a[3, 3] - (win * tab).sum() / tab.sum()) < 1e-2
+
+
+def _jbf_python(depth, guide, w, ss, cs, ds):
+    """literal port of JointBilateralFilter.cu:4-83 in float32 scalar Python (tiny inputs only)."""
+    H, W = depth.shape
+    r = w // 2
+    S = np.empty((w, w), F)
+    for i in range(w):
+        for j in range(w):
+            S[i, j] = F(math.exp(-F(F((j - r) ** 2) + F((i - r) ** 2)) / F(F(2.0) * F(ss * ss))))
+    out = np.zeros((H, W), F)
+
+    def ex(x):
+        return F(math.exp(float(x)))   # double exp rounded once: within 1 ulp of expf
+
+    for y in range(H):
+        for x in range(W):
+            taps = []
+            for i in range(-r, r + 1):
+                for j in range(-r, r + 1):
+                    xj, yi = x + j, y + i
+                    if 0 <= xj < W and 0 <= yi < H and depth[yi, xj] > 50.0:
+                        cd = F(sum((float(guide[y, x, c]) - float(guide[yi, xj, c])) ** 2 for c in range(3)))
+                        cf = ex(-cd / F(2 * F(cs * cs))) if cs != 0 else F(0)
+                        f = F(1.0)
+                        if S[i + r, j + r] != 0:
+                            f = F(f * S[i + r, j + r])
+                        if cf != 0:
+                            f = F(f * cf)
+                        taps.append((depth[yi, xj], f))
+            wa, wt = F(0), F(0)
+            for d, f in taps:
+                wa = F(wa + F(d * f))
+                wt = F(wt + f)
+            if not wt > 0:
+                continue
+            wa = F(wa / wt)
+            num, den = F(0), F(0)
+            for d, f in taps:
+                dd = F(d - wa)
+                df = ex(-F(dd * dd) / F(F(2.0) * F(ds * ds))) if ds != 0 else F(0)
+                g = f if df == 0 else F(f * df)
+                num = F(num + F(d * g))
+                den = F(den + g)
+            out[y, x] = 0 if den == 0 else F(num / den)
+    return out
+
+
+@pytest.mark.parametrize("params", [(5, 70.0, 50.0, 20.0), (3, 2.0, 7.65, 20.0), (7, 3.0, 25.0, 0.0)])
+def test_jbf_matches_independent_python_port(oracle, frame, params):
+    bgr, depth = frame(3, 160, 120)
+    cb = np.ascontiguousarray(bgr[40:58, 60:84])
+    cd = np.ascontiguousarray(depth[40:58, 60:84])
+    w, ss, cs, ds = params
+    ref = _jbf_python(cd, cb, w, F(ss), F(cs), F(ds))
+    got = oracle.jbf_kernel(cd, cb, w, ss, cs, ds)
+    assert np.array_equal(ref == 0, got == 0)
+    nz = ref != 0
+    assert np.max(np.abs(got[nz] - ref[nz]) / ref[nz]) < 2e-6
+
+
+def test_cv_bilateral_constant_and_rounding(oracle):
+    _, bgr = _flat(10, 12, c=(7, 99, 250))
+    assert np.array_equal(oracle.cv_bilateral(bgr), bgr)
+    # an isolated bright pixel is pulled towards its neighbours but colour weights keep it mostly
+    img = np.zeros((9, 9, 3), np.uint8)
+    img[4, 4] = (30, 30, 30)
+    out = oracle.cv_bilateral(img, 5, 30.0, 30.0)
+    # centre weight 1; 12 neighbours (4 each at space2 = 1, 2, 4) of value 0 with L1 colour distance 90
+    wsum = 1.0 + sum(4 * math.exp(s2 * (-0.5 / 900) + 90 ** 2 * (-0.5 / 900)) for s2 in (1, 2, 4))
+    assert out[4, 4, 0] == round(30 / wsum) == 26
+    assert np.all(out[0, 0] == 0)
+
+
+def test_cv_bilateral_reflect101_border(oracle):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (8, 9, 3), dtype=np.uint8)
+    pad = np.pad(img, ((2, 2), (2, 2), (0, 0)), mode="reflect")     # numpy 'reflect' == BORDER_REFLECT_101
+    ref = oracle.cv_bilateral(pad)[2:-2, 2:-2]
+    assert np.array_equal(oracle.cv_bilateral(img), ref)
+
+
+def test_projective_to_real_formula(oracle, synth):
+    K = synth.intrinsics(64, 48)
+    K[0, 2], K[1, 2] = 31.9, 24.7            # Cx, Cy are TRUNCATED to int (DimensionConvertor.cpp:8-9)
+    depth = np.linspace(0, 4000, 64 * 48, dtype=F).reshape(48, 64)
+    p = oracle.p2r_depth(depth, K)
+    fx = F(K[0, 0])
+    y, x = np.mgrid[0:48, 0:64]
+    ex = ((x.astype(F) - F(31)) / fx) * depth       # subtract, divide, multiply
+    ey = ((F(24) - y.astype(F)) / fx) * depth
+    assert np.array_equal(p["x"], ex.astype(F)) and np.array_equal(p["y"], ey.astype(F))
+    assert np.array_equal(p["z"], depth)
+    back = oracle.r2p(p, K)
+    m = depth >= 1
+    assert np.allclose(back["x"][m], x[m], atol=1e-2) and np.allclose(back["y"][m], y[m], atol=1e-2)
+    assert np.all(back["x"][~m] == -1) and np.all(back["y"][~m] == -1)
+    # the float3 overload applies the same functor to (x,y,z) triples
+    trip = np.stack([x.astype(F), y.astype(F), depth], -1)
+    assert np.array_equal(oracle.p2r_points(trip, K).view(F), p.view(F))
+
+
+def test_buffer2d_update_rule(oracle):
+    b = oracle.Buffer2D(4, 2)
+    assert np.all(b.depth_map() == 0) and np.all(b.weight_map() == 0)
+    f1 = np.array([[1000, 40, 2000, 0], [500, 500, 500, 500]], F)
+    b.update(f1)
+    assert np.array_equal(b.depth_map(), np.array([[1000, 0, 2000, 0], [500] * 4], F))
+    assert np.array_equal(b.weight_map(), np.array([[1, 0, 1, 0], [1] * 4], F))
+    f2 = np.array([[1004, 1000, 2100, 60], [504, 505.5, 495, 100]], F)
+    b.update(f2)
+    # gate: (float)abs((int)ref - (int)d) < d*0.01 ; update ((ref*(w+1)) + d*w)/(2w+1), w++
+    d, w = b.depth_map(), b.weight_map()
+    assert d[0, 0] == F((F(1000 * 2.0) + F(1004 * 1.0)) / F(3.0)) and w[0, 0] == 2
+    assert d[0, 1] == 1000 and w[0, 1] == 1          # first valid sample seeds the cell
+    assert d[0, 2] == 2000 and w[0, 2] == 1          # |2000-2100| = 100 >= 21 -> rejected
+    assert d[0, 3] == 60 and w[0, 3] == 1
+    # row 1: |500-504| = 4 < 5.04 ok; |(int)500-(int)505.5| = 5 < 5.055 ok (int truncation); 5 < 4.95 no; 400 < 1 no
+    assert w[1, 0] == 2 and w[1, 1] == 2 and w[1, 2] == 1 and w[1, 3] == 1
+    b.insert_depth(f1)
+    assert np.array_equal(b.depth_map(), f1) and np.all(b.weight_map() == 1)
+    b.insert_float2(np.stack([f2, f2 * 0], -1))
+    assert np.array_equal(b.weight_map(), np.array([[0] * 4, [1] * 4], F))   # w = row index (sic)
+
+
+# ---- DASP: independent literal port of calculateLD on a tiny image -----------------------------
+def _tree_argmin(dist, lab):
+    dist, lab = list(dist), list(lab)
+    for step in (8, 4, 2, 1):
+        for t in range(step):
+            if dist[t] > dist[t + step]:
+                dist[t], lab[t] = dist[t + step], lab[t + step]
+    return dist[0], lab[0]
+
+
+def test_tree_argmin_tie_break_is_not_lowest_index():
+    d = [5.0] * 16
+    d[1] = d[4] = 1.0
+    assert _tree_argmin(d, list(range(16)))[1] == 4         # Q4
+    d = [5.0] * 16
+    d[3] = d[9] = 1.0
+    assert _tree_argmin(d, list(range(16)))[1] == 9          # +8 partner of slot 1 wins, then 1 beats 3? no: 9 folds into slot 1
+    nan = float("nan")
+    d = [nan] + [2.0] * 15
+    assert math.isnan(_tree_argmin(d, list(range(16)))[0])   # a NaN in the low slot is never replaced
+
+
+def test_dasp_calculate_ld_matches_python_port(oracle, frame, synth):
+    bgr, depth = frame(5, 64, 48)
+    K = synth.intrinsics(64, 48)
+    pts = oracle.p2r_depth(depth, K)
+    rows, cols = 3, 4
+    ld0, mean, centers = oracle.dasp_steps(bgr, pts, rows, cols)
+    wx, wy = 64 // cols, 48 // rows
+    assert np.array_equal(ld0["l"], (np.arange(48)[:, None] // wy) * cols + np.arange(64)[None, :] // wx)
+    cs, ss, ds = F(100.0), F(20.0), F(200.0)
+    labels, ld = oracle.dasp_calculate_ld(bgr, pts, rows, cols, ld0, mean, centers, cs, ss, ds)
+    sumS = F(F(ss + cs) + ds)
+    kc, ks, kd = F(F(cs / sumS) ** 2), F(F(ss / sumS) ** 2), F(F(ds / sumS) ** 2)
+    win2 = F(F(F(wx + wy) / F(2.0)) ** 2)
+    for (y, x) in [(0, 0), (5, 17), (23, 31), (47, 63), (24, 16), (30, 40), (11, 50)]:
+        l0 = int(ld0["l"][y, x])
+        ccx, ccy = l0 % cols, l0 // cols
+        dist, lab = [], []
+        for ty in range(4):
+            for tx in range(4):
+                rx, ry = ccx - 2 + tx, ccy - 2 + ty
+                if 0 <= rx < cols and 0 <= ry < rows:
+                    m = mean[ry * cols + rx]
+                    c = bgr[y, x].astype(F)
+                    cdist = F(F(F((c[0] - F(m["r"])) ** 2) + F((c[1] - F(m["g"])) ** 2)) + F((c[2] - F(m["b"])) ** 2))
+                    sd = F(np.sqrt(F(F(F(x - m["x"]) ** 2) + F(F(y - m["y"]) ** 2))) * win2)
+                    z, cz = pts["z"][y, x], centers["z"][ry * cols + rx]
+                    dd = F(abs(F(z - cz))) if (z > 50 and cz > 50) else F(0)
+                    dist.append(F(F(F(cdist * kc) + F(sd * ks)) + F(dd * kd)))
+                    lab.append(ry * cols + rx)
+                else:
+                    dist.append(ld0["d"][y, x])
+                    lab.append(l0)
+        d, l = _tree_argmin(dist, lab)
+        if pts["z"][y, x] < 50:
+            d, l = F(0), -1
+        assert labels[y, x] == l and ld["l"][y, x] == l and ld["d"][y, x] == d
+
+
+def test_dasp_sample_clusters_b_channel_quirk(oracle, frame, synth):
+    bgr, depth = frame(5, 64, 48)
+    pts = oracle.p2r_depth(depth, synth.intrinsics(64, 48))
+    _, mean, centers = oracle.dasp_steps(bgr, pts, 3, 4)
+    for k in range(12):
+        x, y = int(mean["x"][k]), int(mean["y"][k])
+        cx, cy = (k % 4) * 16 + 8, (k // 4) * 16 + 8
+        assert cx - 2 <= x <= cx + 1 and cy - 2 <= y <= cy + 1
+        assert mean["r"][k] == bgr[y, x, 0] and mean["g"][k] == bgr[y, x, 1]
+        assert mean["b"][k] == (int(bgr[y, x, 0]) + 2) % 256       # sic: DepthAdaptiveSuperpixel.cu:159
+        assert centers[k] == pts[y, x]
+
+
+def test_dasp_geometry_guard(oracle, frame, synth):
+    bgr, depth = frame(5, 64, 48)
+    pts = oracle.p2r_depth(depth, synth.intrinsics(64, 48))
+    with pytest.raises(ValueError):
+        oracle.dasp_segmentation(bgr, pts, 15, 20, synth.intrinsics(64, 48), 1.0, 1.0, 1.0, 1)   # window 3x3 < 4
+
+
+# ---- K9: the literal in-place raster-order port agrees with snapshot semantics on isolated edges ----
+def _edge_refining_inplace(cl, labels, depth, window=7):
+    """sequential raster-order execution of EdgeRefinedSuperpixel.cu:4-102 (one legal schedule of the
+    racy kernel when no two sources touch the same cells)."""
+    H, W = labels.shape
+    L, D = labels.copy(), depth.copy()
+    for dirn in (0, 1):
+        ln = W if dirn == 0 else H
+        for y in range(H):
+            for x in range(W):
+                pos = x if dirn == 0 else y
+                def at(a, k):
+                    return a[y, k] if dirn == 0 else a[k, x]
+                def put(a, k, v):
+                    if dirn == 0:
+                        a[y, k] = v
+                    else:
+                        a[k, x] = v
+                if not pos + 1 < ln or at(L, pos) == at(L, pos + 1):
+                    continue
+                cur = at(cl, pos)
+                tgt, dist = cur, 0
+                while (pos - dist >= 0 or pos + dist < ln) and tgt == cur and dist <= window // 2:
+                    tp = pos - dist
+                    if tp >= 0:
+                        tgt = at(cl, tp)
+                    if tgt != cur:
+                        lab = at(L, pos + 1)
+                        for i in range(tp + 1, pos + 1):
+                            put(L, i, lab)
+                            if abs(F(at(D, i) - at(D, i + 1))) > F(at(D, i) * F(0.1)):
+                                put(D, i, F(0))
+                        break
+                    tp = pos + dist
+                    if tp < ln:
+                        tgt = at(cl, tp)
+                    if tgt != cur:
+                        lab = at(L, pos)
+                        for i in range(pos + 1, tp):
+                            put(L, i, lab)
+                            if abs(F(at(D, i) - at(D, i - 1))) > F(at(D, i) * F(0.1)):
+                                put(D, i, F(0))
+                        break
+                    dist += 1
+    return L, D
+
+
+def test_edge_refining_isolated_edges_match_inplace_port(oracle):
+    H, W = 12, 40
+    cl = np.zeros((H, W), np.int32)
+    dl = np.zeros((H, W), np.int32)
+    depth = np.full((H, W), 1000, F)
+    cl[:, 12:] = 1                       # colour edge at x=12
+    dl[:, 10:] = 1                       # depth edge at x=10: 2 px left of the colour edge -> right branch
+    depth[:, 10:] = 1500
+    cl[:, 30:] = 2                       # colour edge at x=30
+    dl[:, 32:] = 2                       # depth edge 2 px right of it -> left branch
+    depth[:, 32:] = 800
+    ref_l, ref_d = _edge_refining_inplace(cl, dl, depth)
+    got_l, got_d = oracle.ers_edge_refining(cl, dl, depth)
+    assert np.array_equal(got_l, ref_l) and np.array_equal(got_d, ref_d)
+    # the depth boundary snapped onto the colour boundary
+    assert np.all(got_l[:, 10:12] == 0) and np.all(got_l[:, 30:32] == 2)
+    # relabelled pixels whose depth jumps > 10 % are zeroed; the right branch cascades
+    assert np.all(got_d[:, 10:12] == 0)
+    assert np.all(got_d[:, 31] == 0) and np.all(got_d[:, 30] == 1500)   # left branch does not cascade
+
+
+def test_edge_refining_no_colour_edge_nearby_is_noop(oracle):
+    cl = np.zeros((8, 20), np.int32)
+    dl = np.zeros((8, 20), np.int32)
+    dl[:, 10:] = 1
+    depth = np.full((8, 20), 900, F)
+    got_l, got_d = oracle.ers_edge_refining(cl, dl, depth)
+    assert np.array_equal(got_l, dl) and np.array_equal(got_d, depth)
+
+
+def test_enhance_mutating_sigma_and_flat_patch(oracle):
+    """Q6: on an exactly flat patch dev == 0, the colour sigma decays 0.3x per valid tap until
+    2*sigma^2 underflows: cd == 0 taps then give 0/0 = NaN (49 valid taps -> NaN), windows with
+    fewer than 47 valid taps stay finite."""
+    depth, bgr = _flat(12, 12, d=1024.0)     # power of two: the weighted average is exact
+    labels = np.zeros((12, 12), np.int32)
+    out = oracle.ers_enhance(depth, bgr, labels)
+    inner = out[3:9, 3:9]
+    assert np.all(np.isnan(inner))
+    assert np.all(out[0, :] == 1024.0) and np.all(out[:, 0] == 1024.0)
+    # with deviation the adaptive sigma floors the decay and everything stays finite
+    rng = np.random.default_rng(1)
+    noisy = (depth + rng.normal(0, 3, depth.shape)).astype(F)
+    assert np.all(np.isfinite(oracle.ers_enhance(noisy, bgr, labels)))
+
+
+def test_mean_3d_error(oracle):
+    a = np.zeros((2, 3, 3), F)
+    b = np.zeros((2, 3, 3), F)
+    a[..., 2] = 1000
+    b[..., 2] = 1003
+    b[0, 0, 2] = 10        # invalid in truth -> excluded
+    a[1, 1] = (4, 0, 1000)
+    b[1, 1] = (0, 3, 1000)
+    e, n = oracle.mean_3d_error(a, b)
+    assert n == 5 and abs(e - (3 * 4 + 5) / 5) < 1e-6
