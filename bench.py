@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Throughput of the joint-bilateral hot path on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one JointBilateralFilter::Process (K0 colour pre-smoothing + K1 joint bilateral filter)
+over one batch of synthetic RGB-D frames that is already resident in HBM.  At N=1 the workload is
+BASELINE config 2's filter on a batch of 640x480 frames (64 frames per GPU: at N=8 that is config 4,
+512 frames sharded 8 ways; weak scaling, no data-path collective — frames are independent units;
+the only exchange is one broadcast of the parameter block from rank 0).
+
+One JSON line is printed by rank 0; besides the contract fields it carries
+  roofline     — the dominant kernel (K1) against the HBM roofline: algorithmic 11 B/pixel
+                 (4 B depth read + 3 B packed-BGR guide read + 4 B filtered write) x pixels per launch
+                 / its average launch duration, measured with HIP events on the launch stream
+                 inside the timed region;
+  cpu_baseline — the CPU oracle (a scalar port of the CUDA kernels; the reference has no CPU path)
+                 timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "Mpixels/sec joint-bilateral filtered (640x480 & 1080p); % HBM roofline"
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+K1_BYTES_PER_PX = 11.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-gpu", type=int, default=64)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--window", type=int, default=11, help="BASELINE 'radius=5' -> 2*5+1")
+    ap.add_argument("--spatial-sigma", type=float, default=3.0)
+    ap.add_argument("--color-sigma", type=float, default=7.65, help="sigma_r=0.03 of the 0..255 range")
+    ap.add_argument("--depth-sigma", type=float, default=20.0)
+    ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--distinct-frames", type=int, default=8, help="distinct synthetic frames, tiled to the batch")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 1080p / reference-constant side measurements")
+    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    return ap.parse_args()
+
+
+def make_inputs(synth, torch, first_seed, n, w, h, distinct):
+    distinct = max(1, min(distinct, n))
+    bgr, depth = synth.make_batch(first_seed, distinct, w, h)
+    reps = -(-n // distinct)
+    bgr = np.tile(bgr, (reps, 1, 1, 1))[:n]
+    depth = np.tile(depth, (reps, 1, 1))[:n]
+    return torch.from_numpy(bgr).cuda(), torch.from_numpy(depth).cuda()
+
+
+def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier):
+    """W untimed + exactly K timed steps; returns (wall seconds, K0 ms list, K1 ms list)."""
+    def step(evs=None):
+        if evs:
+            evs[0].record()
+        jbf.presmooth_batch(color, smooth)          # K0  (== what kde_jbf_process_batch launches)
+        if evs:
+            evs[1].record()
+        jbf.filter_batch(depth, smooth, out)        # K1
+        if evs:
+            evs[2].record()
+
+    for _ in range(warmup):
+        step()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(evs[i])
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    k0 = [e[0].elapsed_time(e[1]) for e in evs]
+    k1 = [e[1].elapsed_time(e[2]) for e in evs]
+    return dt, k0, k1
+
+
+def cpu_baseline(args, synth, seconds):
+    from oracle import oracle as O
+    O.build()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    O.set_threads(cores)
+    bgr, depth = synth.make_frame(0, args.width, args.height)
+    O.jbf_process(depth, bgr, args.window, args.spatial_sigma, args.color_sigma, args.depth_sigma)   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.jbf_process(depth, bgr, args.window, args.spatial_sigma, args.color_sigma, args.depth_sigma)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds and n >= 2:
+            break
+    return {"value": n * args.width * args.height / el / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"{n} x ({args.width}x{args.height}) frames of the same Process (K0+K1, window {args.window}) "
+                      f"through oracle/kde_oracle.c, OpenMP over rows, {el:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from kinectdepthmapenhancement_amd import filters, sharding, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"WORLD_SIZE={world} != --gpus {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+    barrier = dist.barrier if world > 1 else (lambda: None)
+
+    # ---- parameter block: rank 0 decides, everyone receives the same bytes --------------------------
+    p = filters.JointBilateralFilter.default_params()
+    p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma = args.window, args.spatial_sigma, args.color_sigma, args.depth_sigma
+    probe = filters.JointBilateralFilter(8, 8, p)
+    blk = sharding.pack_params(p, table=probe.spatial_table()) if rank == 0 else np.zeros(sharding.BLOCK_LEN)
+    blk = sharding.broadcast_params(blk)
+    p, _, _, _, table0 = sharding.unpack_params(blk)
+    replicas_only = False
+    if not np.array_equal(filters.JointBilateralFilter(8, 8, p).spatial_table(), table0):
+        replicas_only = True        # would mean ranks disagree on the host-computed table: flag the run
+
+    # ---- this rank's shard of the global batch ------------------------------------------------------
+    total_frames = args.frames_per_gpu * world
+    first, count = sharding.partition(total_frames, world)[rank]
+    W, H = args.width, args.height
+    color, depth = make_inputs(synth, torch, first, count, W, H, args.distinct_frames)
+    smooth = torch.empty_like(color)
+    out = torch.empty_like(depth)
+    jbf = filters.JointBilateralFilter(W, H, p, max_batch=count)
+    if args.variant >= 0:
+        jbf.set_variant(args.variant)
+
+    dt, k0_ms, k1_ms = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier)
+    dt = sharding.allreduce_max(dt)
+    checksum = sharding.allreduce_sum([float(out.double().sum().item()), float(count)])
+
+    if rank == 0:
+        px_per_launch = count * W * H
+        k1_avg_ms = float(np.mean(k1_ms))
+        achieved = K1_BYTES_PER_PX * px_per_launch / (k1_avg_ms * 1e-3) / 1e9
+        traffic = None
+        if os.path.exists(args.pmc_json):
+            try:
+                traffic = json.load(open(args.pmc_json)).get("k1_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": METRIC,
+            "value": total_frames * W * H * args.steps / dt / 1e6,
+            "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"JointBilateralFilter::Process (K0 pre-smooth 5/30/30 + K1) on {total_frames} x {W}x{H} "
+                            f"synthetic RGB-D frames ({count} per GPU), window {p.window_size} (radius {p.window_size // 2}), "
+                            f"sigma_s {p.spatial_sigma:g} px, sigma_r {p.color_sigma:g}/255, sigma_d {p.depth_sigma:g} mm",
+                "frames_per_gpu": count, "width": W, "height": H, "window": p.window_size,
+                "sharding": f"contiguous frame blocks x{world}, params broadcast from rank 0" + (" [REPLICAS ONLY]" if replicas_only else ""),
+                "kernel_variant": filters.JointBilateralFilter.variants()[args.variant] if args.variant >= 0 else "auto",
+            },
+            "roofline": {"bound": "hbm", "kernel": "K1 joint_bilateral_filtering", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": K1_BYTES_PER_PX * px_per_launch,
+                         "avg_launch_ms": k1_avg_ms, "k0_avg_launch_ms": float(np.mean(k0_ms))},
+            "checksum": {"sum_filtered_mm": checksum[0], "frames": int(checksum[1])},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            res["cpu_baseline"] = cpu_baseline(args, synth, args.cpu_seconds)
+        if world == 1 and not args.no_extra:
+            res["also"] = side_measurements(torch, filters, synth, args)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def side_measurements(torch, filters, synth, args):
+    """not the headline: K1 alone at 1080p / window 19 (BASELINE config 3) and with the reference's
+    compile-time constants (window 5, sigma 70/50/20) on the VGA batch; same event timing."""
+    out = {}
+
+    def run(name, w, h, n, distinct, window, ss, cs, ds):
+        p = filters.JointBilateralFilter.default_params()
+        p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma = window, ss, cs, ds
+        color, depth = make_inputs(synth, torch, 1000, n, w, h, distinct)
+        smooth, res = torch.empty_like(color), torch.empty_like(depth)
+        jbf = filters.JointBilateralFilter(w, h, p, max_batch=n)
+        if args.variant >= 0:
+            jbf.set_variant(args.variant)
+        steps = max(3, min(args.steps, 10))
+        dt, k0, k1 = time_steps(torch, jbf, depth, color, smooth, res, steps, 2, lambda: None)
+        px = n * w * h
+        k1m = float(np.mean(k1))
+        out[name] = {"frames": n, "width": w, "height": h, "window": window,
+                     "process_mpix_s": px * steps / dt / 1e6, "k1_mpix_s": px / (k1m * 1e-3) / 1e6,
+                     "k1_avg_launch_ms": k1m, "k0_avg_launch_ms": float(np.mean(k0)),
+                     "k1_hbm_frac": K1_BYTES_PER_PX * px / (k1m * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    run("fhd_w19_config3", 1920, 1080, 8, 2, 19, 3.0, 7.65, 20.0)
+    run("vga_reference_constants_w5", 640, 480, 64, 8, 5, 70.0, 50.0, 20.0)
+    # empirical HBM ceiling: float4 copy of 1 GiB (read + write)
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
+    b = torch.empty_like(a)
+    for _ in range(2):
+        filters.hbm_copy(a, b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        filters.hbm_copy(a, b)
+    e1.record()
+    torch.cuda.synchronize()
+    out["float4_copy_GBs"] = 2 * 4 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return out
+
+
+if __name__ == "__main__":
+    main()

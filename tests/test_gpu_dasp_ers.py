@@ -1,0 +1,192 @@
+"""DASP (K5-K8), ERS (K9, K10) and the RGBF / SPDSR pipelines: HIP vs CPU oracle.
+Integer outputs (labels, cluster records) must be exact; float cluster centres use the same summation
+order as the oracle and are compared exactly; K10 depth uses the 1e-4 relative bar."""
+import numpy as np
+import pytest
+
+from conftest import assert_depth_close
+from gpu_util import dev, host, ld_records, mean_records, pts_as_f32
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F(torch_cuda):
+    from kinectdepthmapenhancement_amd import filters
+    return filters
+
+
+def _inputs(oracle, synth, frame, seed, w, h):
+    bgr, depth = frame(seed, w, h)
+    K = synth.intrinsics(w, h)
+    pts = oracle.p2r_depth(depth, K)
+    return bgr, depth, K, pts
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(size=(640, 480), rows=15, cols=20, sig=(200.0, 40.0, 0.0), it=1),     # RGBF's SP call
+    dict(size=(640, 480), rows=15, cols=20, sig=(100.0, 20.0, 200.0), it=1),   # RGBF's DASP call
+    dict(size=(640, 480), rows=15, cols=20, sig=(0.0, 10.0, 200.0), it=5),     # SPDSR's DASP call
+    dict(size=(320, 240), rows=7, cols=9, sig=(200.0, 10.0, 0.0), it=3),       # non-dividing grid (ragged windows)
+    dict(size=(70, 50), rows=3, cols=5, sig=(100.0, 20.0, 200.0), it=2),
+])
+def test_dasp_segmentation_exact(torch_cuda, F, oracle, synth, frame, cfg):
+    w, h = cfg["size"]
+    bgr, depth, K, pts = _inputs(oracle, synth, frame, 11, w, h)
+    d = F.DepthAdaptiveSuperpixel(w, h)
+    d.SetParametor(cfg["rows"], cfg["cols"], K)
+    d.Segmentation(dev(torch_cuda, bgr), dev(torch_cuda, pts_as_f32(pts)), *cfg["sig"], cfg["it"])
+    labels, ld, mean, centers = oracle.dasp_segmentation(bgr, pts, cfg["rows"], cfg["cols"], K, *cfg["sig"], cfg["it"])
+    assert np.array_equal(host(d.getLabelDevice()), labels)
+    gl = ld_records(d.getLDDevice())
+    assert np.array_equal(gl["l"], ld["l"]) and np.array_equal(gl["d"], ld["d"])
+    gm = mean_records(d.getMeanDataDevice())
+    for f in ("r", "g", "b", "x", "y", "size"):
+        assert np.array_equal(gm[f], mean[f]), f
+    assert np.array_equal(host(d.getCentersDevice()), pts_as_f32(centers), equal_nan=True)
+
+
+def test_dasp_geometry_guard(torch_cuda, F, synth):
+    from kinectdepthmapenhancement_amd import KdeError
+    d = F.DepthAdaptiveSuperpixel(64, 48)
+    with pytest.raises(KdeError):
+        d.SetParametor(15, 20, synth.intrinsics(64, 48))       # 3x3 windows: 4x4 candidate grid leaves the image
+    with pytest.raises(KdeError):
+        d.Segmentation(torch_cuda.zeros((48, 64, 3), dtype=torch_cuda.uint8, device="cuda"),
+                       torch_cuda.zeros((48, 64, 3), device="cuda"), 1.0, 1.0, 1.0, 1)   # SetParametor not called
+
+
+@pytest.mark.parametrize("size", [(640, 480), (70, 50)])
+def test_ers_edge_refining_and_enhancement(torch_cuda, F, oracle, synth, frame, size):
+    w, h = size
+    rows, cols = (15, 20) if w == 640 else (3, 5)
+    bgr, depth, K, pts = _inputs(oracle, synth, frame, 12, w, h)
+    sp = oracle.dasp_segmentation(bgr, pts, rows, cols, K, 200.0, 40.0, 0.0, 1)[0]
+    da = oracle.dasp_segmentation(bgr, pts, rows, cols, K, 100.0, 20.0, 200.0, 1)[0]
+    ers = F.EdgeRefinedSuperpixel(w, h)
+    ers.EdgeRefining(dev(torch_cuda, sp), dev(torch_cuda, da), dev(torch_cuda, depth), dev(torch_cuda, bgr))
+    rl, rd9 = oracle.ers_edge_refining(sp, da, depth)
+    assert np.array_equal(host(ers.getRefinedLabels_Device()), rl)            # K9 labels exact
+    assert np.array_equal(host(ers.getEdgeStageDepth_Device()), rd9)          # K9 depth exact (only zeroing)
+    assert (rl != da).sum() > 0 and (rd9 != depth).sum() > 0                  # the case actually exercises K9
+    ref = oracle.ers_enhance(rd9, bgr, rl)
+    assert_depth_close(host(ers.getRefinedDepth_Device()), ref, 1e-4, what="K10")
+    assert np.array_equal(ers.getRefinedLabels_Host(), rl)
+    assert_depth_close(ers.getRefinedDepth_Host(), ref, 1e-4, what="K10 host copy")
+
+
+def test_ers_crafted_label_boundaries(torch_cuda, F, oracle):
+    """left / right branch, cascade, overlapping write sets in both scan directions."""
+    rng = np.random.default_rng(5)
+    H, W = 64, 96
+    cl = (np.arange(W)[None, :] // 7 + 13 * (np.arange(H)[:, None] // 5)).astype(np.int32)
+    dl = ((np.arange(W)[None, :] + 2) // 7 + 13 * ((np.arange(H)[:, None] + 3) // 5)).astype(np.int32)
+    dl[rng.random((H, W)) < 0.02] = 999                      # speckle: many overlapping sources
+    depth = (800 + 40 * dl + rng.normal(0, 30, (H, W))).astype(np.float32)
+    depth[rng.random((H, W)) < 0.05] = 0
+    bgr = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    ers = F.EdgeRefinedSuperpixel(W, H)
+    ers.EdgeRefining(dev(torch_cuda, cl), dev(torch_cuda, dl), dev(torch_cuda, depth), dev(torch_cuda, bgr))
+    rl, rd9 = oracle.ers_edge_refining(cl, dl, depth)
+    assert np.array_equal(host(ers.getRefinedLabels_Device()), rl)
+    assert np.array_equal(host(ers.getEdgeStageDepth_Device()), rd9)
+    assert_depth_close(host(ers.getRefinedDepth_Device()), oracle.ers_enhance(rd9, bgr, rl), 1e-4, what="K10 crafted")
+
+
+def test_k10_flat_patch_nan_quirk(torch_cuda, F, oracle):
+    """Q6: exactly flat depth + flat colour -> 0/0 after 47 valid taps: NaNs must coincide with the oracle's."""
+    H, W = 24, 40
+    depth = np.full((H, W), 1024.0, np.float32)
+    bgr = np.full((H, W, 3), 9, np.uint8)
+    lab = np.zeros((H, W), np.int32)
+    ers = F.EdgeRefinedSuperpixel(W, H)
+    ers.EdgeRefining(dev(torch_cuda, lab), dev(torch_cuda, lab), dev(torch_cuda, depth), dev(torch_cuda, bgr))
+    ref = oracle.ers_enhance(depth, bgr, lab)
+    got = host(ers.getRefinedDepth_Device())
+    assert np.isnan(ref).sum() > 0
+    assert_depth_close(got, ref, 1e-4, what="K10 NaN quirk")
+
+
+def test_rgbf_pipeline_on_reference_color_fixture(torch_cuda, F, oracle, color_fixture, synth):
+    _, depth = synth.make_frame(1, 640, 480)
+    K = synth.intrinsics(640, 480)
+    pts = oracle.p2r_depth(depth, K)
+    rg = F.RegionGrowingBilateralFilter(640, 480)
+    rg.SetParametor(15, 20, K)
+    rg.Process(dev(torch_cuda, depth), dev(torch_cuda, pts_as_f32(pts)), dev(torch_cuda, color_fixture))
+    ref = oracle.rgbf_process(depth, pts, color_fixture, 15, 20, K)
+    assert np.array_equal(host(rg.getSPLabels_Device()), ref["sp_labels"])
+    assert np.array_equal(host(rg.getDASPLabels_Device()), ref["dasp_labels"])
+    assert np.array_equal(host(rg.getRefinedLabels_Device()), ref["refined_labels"])
+    assert_depth_close(host(rg.getRefinedDepth_Device()), ref["refined_depth"], 1e-4, what="RGBF")
+    assert_depth_close(rg.getRefinedDepth_Host(), ref["refined_depth"], 1e-4, what="RGBF host")
+
+
+def test_full_chain_config5_vga(torch_cuda, F, oracle, synth, frame):
+    """BASELINE config 5 composition at a size the oracle finishes in seconds:
+    projectiveToReal -> JBF.Process -> RGBF.Process fed with the JBF output and its back-projection."""
+    w, h = 640, 480
+    bgr, depth = frame(13, w, h)
+    K = synth.intrinsics(w, h)
+    t = torch_cuda
+    conv = F.DimensionConvertor(); conv.setCameraParameters(K, w, h)
+    jbf = F.JointBilateralFilter(w, h)
+    rg = F.RegionGrowingBilateralFilter(w, h); rg.SetParametor(15, 20, K)
+    color = dev(t, bgr)
+    jbf.Process(dev(t, depth), color)
+    filt = jbf.getFiltered_Device()
+    pts = t.empty((h, w, 3), dtype=t.float32, device="cuda")
+    conv.projectiveToReal(filt, pts)
+    rg.Process(filt, pts, color)
+    got_filt = host(filt)
+    ref_filt, _, ill = oracle.jbf_process(depth, bgr, return_all=True)
+    assert_depth_close(got_filt, ref_filt, 1e-4, ill=ill, what="chain JBF")
+    # downstream stages are compared on the GPU's own JBF output (labels are discontinuous in their input)
+    opts = oracle.p2r_depth(got_filt, K)
+    assert np.array_equal(host(pts), pts_as_f32(opts))
+    ref = oracle.rgbf_process(got_filt, opts, bgr, 15, 20, K)
+    assert np.array_equal(host(rg.getRefinedLabels_Device()), ref["refined_labels"])
+    assert_depth_close(host(rg.getRefinedDepth_Device()), ref["refined_depth"], 1e-4, what="chain RGBF")
+
+
+def test_full_chain_config5_1080p_properties(torch_cuda, F, synth):
+    """the 1080p chain (rows=15, cols=20) runs and satisfies size-independent properties; init_LD's
+    H/32 grid in the reference leaves rows 1056-1079 uninitialised (F8) — here every row is labelled."""
+    w, h = 1920, 1080
+    t = torch_cuda
+    bgr, depth = synth.make_frame(21, w, h)
+    K = synth.intrinsics(w, h)
+    conv = F.DimensionConvertor(); conv.setCameraParameters(K, w, h)
+    jbf = F.JointBilateralFilter(w, h)
+    rg = F.RegionGrowingBilateralFilter(w, h); rg.SetParametor(15, 20, K)
+    color, d = dev(t, bgr), dev(t, depth)
+    jbf.Process(d, color)
+    filt = jbf.getFiltered_Device()
+    pts = t.empty((h, w, 3), dtype=t.float32, device="cuda")
+    conv.projectiveToReal(filt, pts)
+    rg.Process(filt, pts, color)
+    lab = rg.getRefinedLabels_Device()
+    assert int(lab.min()) >= -1 and int(lab.max()) < 300
+    assert int((lab[1056:] >= 0).sum()) > 0.5 * lab[1056:].numel()
+    out = rg.getRefinedDepth_Device()
+    fin = out[t.isfinite(out)]
+    assert fin.max() <= filt.max() * 1.00001 and (out != 0).float().mean() > 0.8
+    again = out.clone()
+    rg.Process(filt, pts, color)
+    assert t.equal(t.nan_to_num(rg.getRefinedDepth_Device()), t.nan_to_num(again))      # deterministic (race-free)
+
+
+def test_spdsr_head_and_unbuilt_tail(torch_cuda, F, oracle, synth, frame):
+    from kinectdepthmapenhancement_amd import KdeError
+    w, h = 320, 240
+    bgr, depth, K, pts = _inputs(oracle, synth, frame, 14, w, h)
+    sp = F.SPDepthSuperResolution(w, h)
+    sp.SetParametor(6, 8, K)
+    sp.Process(dev(torch_cuda, depth), dev(torch_cuda, pts_as_f32(pts)), dev(torch_cuda, bgr))
+    rl, rd, rp = oracle.spdsr_head(depth, pts, bgr, 6, 8, K)
+    assert np.array_equal(host(sp.getRefinedLabels_Device()), rl)
+    got = host(sp.getRefinedDepth_Device())
+    assert_depth_close(got, rd, 1e-4, what="SPDSR head depth")
+    assert np.array_equal(host(sp.getEdgeEnhanced3DPoints_Device()), pts_as_f32(oracle.p2r_depth(got, K)), equal_nan=True)
+    with pytest.raises(KdeError):
+        sp.getOptimizedPoints_Device()

@@ -1,0 +1,41 @@
+"""HIP path vs the committed golden crops (tests/golden/golden_crops.npz, produced by the oracle)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_depth_close
+from gpu_util import dev, host
+
+pytestmark = pytest.mark.gpu
+
+
+def test_golden_crops(torch_cuda, synth):
+    from kinectdepthmapenhancement_amd import filters as F
+    t = torch_cuda
+    g = np.load(os.path.join(GOLDEN, "golden_crops.npz"))
+    cb, cd = g["bgr"], g["depth"]
+    Kc = synth.intrinsics(64, 48)
+    jbf = F.JointBilateralFilter(64, 48)
+    jbf.Process(dev(t, cd), dev(t, cb))
+    assert np.array_equal(host(jbf.getSmoothImage_Device()), g["k0_smooth"])
+    assert_depth_close(host(jbf.getFiltered_Device()), g["jbf_process"], 1e-4, what="golden Process")
+    p = F.JointBilateralFilter.default_params()
+    p.window_size, p.spatial_sigma, p.color_sigma, p.presmooth = 11, 3.0, 7.65, 0
+    j2 = F.JointBilateralFilter(64, 48, p)
+    out = t.empty((1, 48, 64), dtype=t.float32, device="cuda")
+    j2.filter_batch(dev(t, cd[None]), dev(t, cb[None]), out)
+    assert_depth_close(host(out)[0], g["k1_jbf_w11_s3_c7p65"], 1e-4, what="golden w11")
+    conv = F.DimensionConvertor(); conv.setCameraParameters(Kc, 64, 48)
+    pts = t.empty((48, 64, 3), dtype=t.float32, device="cuda")
+    conv.projectiveToReal(dev(t, cd), pts)
+    assert np.array_equal(host(pts), g["k2_points"])
+    rg = F.RegionGrowingBilateralFilter(64, 48); rg.SetParametor(3, 4, Kc)
+    rg.Process(dev(t, cd), pts, dev(t, cb))
+    assert np.array_equal(host(rg.getSPLabels_Device()), g["k7_sp_labels"])
+    assert np.array_equal(host(rg.getDASPLabels_Device()), g["k7_dasp_labels"])
+    assert np.array_equal(host(rg.getRefinedLabels_Device()), g["rgbf_refined_labels"])
+    assert_depth_close(host(rg.getRefinedDepth_Device()), g["rgbf_refined_depth"], 1e-4, what="golden RGBF")
+    mrf = F.MarkovRandomField(64, 48)
+    mrf.Process(dev(t, cd), dev(t, cb))
+    assert_depth_close(host(mrf.getFiltered_Device()), g["mrf"], 1e-4, what="golden MRF")

@@ -1,0 +1,173 @@
+"""K0 / K1 / Process parity: HIP (through the C ABI) vs the CPU oracle.
+
+Bar: exact equality for K0's u8 output; for float depth <= 1e-4 relative on
+non-zero outputs with an identical zero / non-zero mask.  Pixels the oracle flags as
+ill-conditioned (every surviving weight denormal-scale) are excluded and must be rare."""
+import numpy as np
+import pytest
+
+from conftest import assert_depth_close
+from gpu_util import dev, host
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def F(torch_cuda):
+    from kinectdepthmapenhancement_amd import filters
+    return filters
+
+
+def params(F, w=5, ss=70.0, cs=50.0, ds=20.0, pre=1, pk=5, pc=30.0, ps=30.0):
+    p = F.JointBilateralFilter.default_params()
+    p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma = w, ss, cs, ds
+    p.presmooth, p.presmooth_kernel_size, p.presmooth_sigma_color, p.presmooth_sigma_spatial = pre, pk, pc, ps
+    return p
+
+
+def test_presmooth_k0_is_bit_exact(torch_cuda, F, oracle, frame, color_fixture):
+    for bgr in (color_fixture, frame(2)[0], frame(4, 70, 50)[0], frame(4, 33, 9)[0]):
+        h, w, _ = bgr.shape
+        jbf = F.JointBilateralFilter(w, h)
+        out = torch_cuda.empty((1, h, w, 3), dtype=torch_cuda.uint8, device="cuda")
+        jbf.presmooth_batch(dev(torch_cuda, bgr[None]), out)
+        assert np.array_equal(host(out)[0], oracle.cv_bilateral(bgr, 5, 30.0, 30.0))
+
+
+@pytest.mark.parametrize("ksize,sc,ss", [(3, 10.0, 5.0), (7, 60.0, 2.0), (9, 25.0, 25.0), (0, 30.0, 1.7)])
+def test_presmooth_other_kernel_sizes(torch_cuda, F, oracle, frame, ksize, sc, ss):
+    bgr = frame(6, 96, 64)[0]
+    jbf = F.JointBilateralFilter(96, 64, params(F, pk=ksize, pc=sc, ps=ss))
+    out = torch_cuda.empty((1, 64, 96, 3), dtype=torch_cuda.uint8, device="cuda")
+    jbf.presmooth_batch(dev(torch_cuda, bgr[None]), out)
+    assert np.array_equal(host(out)[0], oracle.cv_bilateral(bgr, ksize, sc, ss))
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(w=5, ss=70.0, cs=50.0, ds=20.0),      # the reference's compile-time constants
+    dict(w=11, ss=3.0, cs=7.65, ds=20.0),      # BASELINE "radius=5 sigma_s=3 sigma_r=0.03"
+    dict(w=19, ss=3.0, cs=7.65, ds=20.0),      # BASELINE "radius=9"
+    dict(w=7, ss=30.0, cs=50.0, ds=70.0),
+    dict(w=3, ss=1.0, cs=0.0, ds=20.0),        # colour term off
+    dict(w=5, ss=70.0, cs=50.0, ds=0.0),       # depth term off (Q3)
+    dict(w=1, ss=70.0, cs=50.0, ds=20.0),
+    dict(w=31, ss=0.5, cs=30.0, ds=40.0),      # spatial table underflows to 0 at the rim -> factor skipped
+])
+def test_filter_k1_matches_oracle(torch_cuda, F, oracle, frame, cfg):
+    bgr, depth = frame(2, 320, 240)
+    jbf = F.JointBilateralFilter(320, 240, params(F, cfg["w"], cfg["ss"], cfg["cs"], cfg["ds"], pre=0))
+    out = torch_cuda.empty((1, 240, 320), dtype=torch_cuda.float32, device="cuda")
+    jbf.filter_batch(dev(torch_cuda, depth[None]), dev(torch_cuda, bgr[None]), out)
+    ref, ill = oracle.jbf_kernel(depth, bgr, cfg["w"], cfg["ss"], cfg["cs"], cfg["ds"], return_ill=True)
+    assert ill.mean() < 1e-3
+    assert_depth_close(host(out)[0], ref, RTOL, ill=ill, what=f"K1 {cfg}")
+    assert np.array_equal(jbf.spatial_table(), oracle.spatial_table(cfg["w"], cfg["ss"]))
+
+
+def test_process_on_reference_color_fixture(torch_cuda, F, oracle, color_fixture, synth):
+    """BASELINE config 2: the single 640x480 frame (input/color.jpg decode + synthetic depth seed 1,
+    depth.xml being absent), JointBilateralFilter::Process with the reference constants."""
+    _, depth = synth.make_frame(1, 640, 480)
+    jbf = F.JointBilateralFilter(640, 480)
+    jbf.Process(dev(torch_cuda, depth), dev(torch_cuda, color_fixture))
+    ref, smooth, ill = oracle.jbf_process(depth, color_fixture, return_all=True)
+    assert np.array_equal(host(jbf.getSmoothImage_Device()), smooth)
+    assert_depth_close(host(jbf.getFiltered_Device()), ref, RTOL, ill=ill, what="Process")
+    assert_depth_close(jbf.getFiltered_Host(), ref, RTOL, ill=ill, what="getFiltered_Host")
+
+
+@pytest.mark.parametrize("size", [(70, 50), (33, 9), (7, 5), (1, 1), (640, 1), (2, 300)])
+def test_ragged_and_tiny_frames(torch_cuda, F, oracle, frame, size):
+    w, h = size
+    bgr, depth = frame(9, max(w, 8), max(h, 8))
+    bgr, depth = np.ascontiguousarray(bgr[:h, :w]), np.ascontiguousarray(depth[:h, :w])
+    jbf = F.JointBilateralFilter(w, h)
+    jbf.Process(dev(torch_cuda, depth), dev(torch_cuda, bgr))
+    ref, ill = oracle.jbf_process(depth, bgr, return_all=True)[::2]
+    assert_depth_close(host(jbf.getFiltered_Device()), ref, RTOL, ill=ill, what=f"{w}x{h}")
+
+
+def test_batch_equals_per_frame_and_is_order_independent(torch_cuda, F, oracle, synth):
+    bgr, depth = synth.make_batch(20, 5, 160, 120)
+    jbf = F.JointBilateralFilter(160, 120, max_batch=5)
+    out = host(jbf.process_batch(dev(torch_cuda, depth), dev(torch_cuda, bgr))).copy()
+    for i in range(5):
+        ref, _, ill = oracle.jbf_process(depth[i], bgr[i], return_all=True)
+        assert_depth_close(out[i], ref, RTOL, ill=ill, what=f"frame {i}")
+    perm = [3, 0, 4, 1, 2]
+    out2 = host(jbf.process_batch(dev(torch_cuda, depth[perm]), dev(torch_cuda, bgr[perm])))
+    assert np.array_equal(out2, out[perm])          # frames are independent units: bitwise
+
+
+def test_edge_cases_invalid_and_q1(torch_cuda, F, oracle):
+    h, w = 40, 48
+    bgr = np.full((h, w, 3), 77, np.uint8)
+    jbf = F.JointBilateralFilter(w, h, params(F, pre=0))
+    out = torch_cuda.empty((1, h, w), dtype=torch_cuda.float32, device="cuda")
+
+    def run(depth):
+        jbf.filter_batch(dev(torch_cuda, depth[None]), dev(torch_cuda, bgr[None]), out)
+        return host(out)[0].copy()
+
+    assert np.all(run(np.zeros((h, w), np.float32)) == 0)                    # all invalid
+    assert np.all(run(np.full((h, w), 50.0, np.float32)) == 0)               # 50 is not > 50
+    d = np.zeros((h, w), np.float32)
+    d[20, 20] = 1234.5                                                       # single valid pixel fills its window
+    o = run(d)
+    assert np.count_nonzero(o) == 25 and np.allclose(o[18:23, 18:23], 1234.5, rtol=1e-6)
+    # Q1: outliers either side of the 288.41 mm underflow threshold
+    for delta in (250.0, 280.0, 295.0, 320.0, 2000.0):
+        d = np.full((h, w), 1000.0, np.float32)
+        d[10, 10] += delta
+        assert_depth_close(run(d), oracle.jbf_kernel(d, bgr), RTOL, what=f"outlier {delta}")
+    d = np.full((h, w), np.nan, np.float32)                                  # NaN depth is "not > 50": ignored
+    d[5:9, 5:9] = 800.0
+    assert_depth_close(run(d), oracle.jbf_kernel(d, bgr), RTOL, what="nan depth")
+
+
+def test_full_size_properties_1080p(torch_cuda, F):
+    """BASELINE-size frames, checked through size-independent properties (no oracle run)."""
+    H, W, n = 1080, 1920, 3
+    t = torch_cuda
+    g = t.Generator(device="cuda").manual_seed(0)
+    bgr = t.randint(0, 256, (n, H, W, 3), dtype=t.uint8, device="cuda", generator=g)
+    jbf = F.JointBilateralFilter(W, H, params(F, 19, 3.0, 7.65, 20.0), max_batch=n)
+    flat = t.full((n, H, W), 1500.0, dtype=t.float32, device="cuda")
+    out = jbf.process_batch(flat, bgr)
+    assert t.allclose(out, flat, rtol=2e-6, atol=0)                          # constant depth -> identity
+    assert t.count_nonzero(jbf.process_batch(t.zeros_like(flat), bgr)) == 0  # all invalid -> zeros
+    depth = 500.0 + 3000.0 * t.rand((n, H, W), device="cuda", generator=g)
+    depth[:, ::7, ::5] = 0
+    a = jbf.process_batch(depth, bgr).clone()
+    valid = depth > 50
+    lo = t.where(valid, depth, t.full_like(depth, 1e9)).amin()
+    hi = depth.amax()
+    nz = a != 0
+    assert a[nz].min() >= lo * (1 - 1e-5) and a[nz].max() <= hi * (1 + 1e-5)   # convex combination of valid taps
+    b = jbf.process_batch(depth.flip(0).contiguous(), bgr.flip(0).contiguous()).flip(0)
+    assert t.equal(a, b)                                                      # frames independent, deterministic
+    # mirror symmetry: filtering the x-flipped frame == x-flipping the filtered frame (symmetric table)
+    am = jbf.process_batch(depth.flip(2).contiguous(), bgr.flip(2).contiguous()).flip(2)
+    rel = ((am - a).abs() / a.abs().clamp_min(1)).max().item()
+    assert rel < 1e-4 and t.equal(am != 0, a != 0)
+
+
+def test_mrf_sibling_filter(torch_cuda, F, oracle, frame):
+    bgr, depth = frame(2, 320, 240)
+    mrf = F.MarkovRandomField(320, 240)
+    mrf.Process(dev(torch_cuda, depth), dev(torch_cuda, bgr))
+    assert_depth_close(host(mrf.getFiltered_Device()), oracle.mrf_kernel(depth, bgr), RTOL, what="MRF")
+
+
+def test_errors_are_reported_not_fatal(torch_cuda, F):
+    from kinectdepthmapenhancement_amd import KdeError
+    jbf = F.JointBilateralFilter(64, 48)
+    with pytest.raises(ValueError):
+        jbf.Process(torch_cuda.zeros((48, 63), device="cuda"), torch_cuda.zeros((48, 64, 3), dtype=torch_cuda.uint8, device="cuda"))
+    with pytest.raises(KdeError):
+        jbf.process_batch(torch_cuda.zeros((2, 48, 64), device="cuda"),
+                          torch_cuda.zeros((2, 48, 64, 3), dtype=torch_cuda.uint8, device="cuda"))   # n > max_batch
+    with pytest.raises(KdeError):
+        F.JointBilateralFilter(64, 48, params(F, w=6))
