@@ -92,14 +92,28 @@ def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier):
     return dt, k0, k1
 
 
+def usable_cores():
+    """threads the CPU leg may really use: the cgroup CPU quota if one is set, else the affinity mask."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    # a one-GPU box of the pool is granted a 16-CPU share of its 256-CPU host (the affinity mask still shows
+    # all of them; 256 OpenMP threads on that share ran 10x slower than 16)
+    return min(n, int(os.environ.get("KDE_CPU_THREADS", "16")))
+
+
 def cpu_baseline(args, synth, seconds):
     from oracle import oracle as O
     O.build()
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = usable_cores()
     O.set_threads(cores)
     bgr, depth = synth.make_frame(0, args.width, args.height)
     O.jbf_process(depth, bgr, args.window, args.spatial_sigma, args.color_sigma, args.depth_sigma)   # warm-up

@@ -148,10 +148,16 @@ def test_full_size_properties_1080p(torch_cuda, F):
     assert a[nz].min() >= lo * (1 - 1e-5) and a[nz].max() <= hi * (1 + 1e-5)   # convex combination of valid taps
     b = jbf.process_batch(depth.flip(0).contiguous(), bgr.flip(0).contiguous()).flip(0)
     assert t.equal(a, b)                                                      # frames independent, deterministic
-    # mirror symmetry: filtering the x-flipped frame == x-flipping the filtered frame (symmetric table)
-    am = jbf.process_batch(depth.flip(2).contiguous(), bgr.flip(2).contiguous()).flip(2)
-    rel = ((am - a).abs() / a.abs().clamp_min(1)).max().item()
-    assert rel < 1e-4 and t.equal(am != 0, a != 0)
+    # mirror symmetry (symmetric spatial table): filtering the x-flipped frame == x-flipping the filtered
+    # frame up to summation order.  Checked on a smooth surface: on wild data a tap sitting on the Q1
+    # underflow threshold (|d - avg| = 288.41 mm) legitimately flips with the last ulp of the average.
+    yy, xx = t.meshgrid(t.arange(H, device="cuda"), t.arange(W, device="cuda"), indexing="ij")
+    smooth = (1000.0 + 0.3 * xx + 0.2 * yy)[None].repeat(n, 1, 1) + 6.0 * t.rand((n, H, W), device="cuda", generator=g) - 3.0
+    smooth[:, ::7, ::5] = 0
+    s1 = jbf.process_batch(smooth.contiguous(), bgr).clone()
+    s2 = jbf.process_batch(smooth.flip(2).contiguous(), bgr.flip(2).contiguous()).flip(2)
+    rel = ((s2 - s1).abs() / s1.abs().clamp_min(1)).max().item()
+    assert rel < 1e-4 and t.equal(s2 != 0, s1 != 0)
 
 
 def test_mrf_sibling_filter(torch_cuda, F, oracle, frame):
