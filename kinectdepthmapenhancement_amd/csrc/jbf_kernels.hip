@@ -267,11 +267,18 @@ __global__ __launch_bounds__(kThreads) void mrf_kernel(MrfDev a)
 
 }  // namespace
 
-int jbf_variant_count() { return 1; }
-const char* jbf_variant_name(int v) { return v == 0 ? "generic-32x8-1px" : "?"; }
+int jbf_variant_count() { return 1 + jbf_fast_variant_count(); }
+const char* jbf_variant_name(int v) { return v == 0 ? "generic-32x8-1px" : jbf_fast_variant_name(v - 1); }
 
 int launch_jbf(const JbfLaunch& a, hipStream_t s)
 {
+    // variant -1: tuned kernel when one exists for this window and parameter regime, else the generic one
+    if (a.variant > 0) {
+        if (!jbf_fast_supported(a)) return fail(KDE_ERR_INVALID, "jbf: tuned variants need non-zero sigmas and a built window");
+        return launch_jbf_fast(a, a.variant - 1, a.table_host, s);
+    }
+    if (a.variant < 0 && jbf_fast_supported(a))
+        return launch_jbf_fast(a, jbf_fast_default_variant(a), a.table_host, s);
     JbfDev d;
     d.depth = a.depth;
     d.guide = a.guide;

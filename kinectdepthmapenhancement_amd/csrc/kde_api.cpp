@@ -228,6 +228,8 @@ static int jbf_filter(kde_jbf* h, int n, const float* depth, const uint8_t* guid
     a.guide = guide;
     a.out = out;
     a.s_eff = h->s_eff.p;
+    a.table_host = h->table.data();
+    a.spatial_sigma = h->p.spatial_sigma;
     a.color_sigma = h->p.color_sigma;
     a.depth_sigma = h->p.depth_sigma;
     a.color_den = h->color_den;

@@ -113,13 +113,21 @@ struct JbfLaunch {
     const uint8_t* guide;      // [n][H][W][3]
     float* out;                // [n][H][W]
     const float* s_eff;        // device, window^2 (zeros replaced by 1)
-    float color_sigma, depth_sigma;
+    const float* table_host;   // host, window^2 (calcSpatialFilter as computed)
+    float spatial_sigma, color_sigma, depth_sigma;
     float color_den, depth_den;    // 2*sigma^2 as the reference forms it (float)
     int cd_skip;               // colour factor skipped (== underflow to 0) when cd >= cd_skip
     float d2_skip;             // depth factor skipped when (d_q - wavg)^2 >= d2_skip
     int variant;
 };
 int launch_jbf(const JbfLaunch& a, hipStream_t s);
+// tuned variants (jbf_fast.hip); variant ids there are 0-based, the public id is +1 (0 = generic kernel)
+int jbf_fast_variant_count();
+const char* jbf_fast_variant_name(int v);
+int jbf_fast_variant_window(int v);
+int jbf_fast_default_variant(const JbfLaunch& l);
+bool jbf_fast_supported(const JbfLaunch& l);
+int launch_jbf_fast(const JbfLaunch& l, int variant, const float* table_host, hipStream_t s);
 int jbf_variant_count();
 const char* jbf_variant_name(int v);
 

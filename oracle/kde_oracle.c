@@ -193,8 +193,14 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                             float dd = dq - w_average;
                             float depth_diff = dd * dd;
                             float depth_filter = 0.0f; /* Q3: uninitialised in the reference */
-                            if (depth_sigma != 0.0f)
-                                depth_filter = expf(-depth_diff / (2.0f * (depth_sigma * depth_sigma)));
+                            if (depth_sigma != 0.0f) {
+                                float xarg = depth_diff / (2.0f * (depth_sigma * depth_sigma));
+                                depth_filter = expf(-xarg);
+                                /* the factor jumps from ~1e-45 to "skipped" (= 1) where expf underflows
+                                 * (x = 150 ln 2): a tap this close to the jump makes the pixel
+                                 * discontinuous in the last ulps of w_average */
+                                if (fabsf(xarg - 103.972077f) <= 103.972077f * 1e-4f) flag |= 2;
+                            }
                             float filter = 1.0f;
                             float s = spatial[(i + hw) * window_size + (j + hw)];
                             if (s != 0.0f) filter *= s;
@@ -207,10 +213,56 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                 }
                 if (denominator == 0.0f) out = 0.0f;
                 else out = numerator / denominator;
-                if (denominator < 1e-30f) flag = 1;
+                if (denominator < 1e-30f) flag |= 1;
             }
             filtered[(size_t)y * width + x] = out;
-            if (ill) ill[(size_t)y * width + x] = flag;
+            if (ill) {
+                /* conditioning probe: the same two passes in binary64 (same skip decisions up to the
+                 * threshold band flagged above).  Where the float32 result of the restatement itself
+                 * moves by more than 2e-5 against it, the pixel amplifies 1e-7 roundings by > 200x and
+                 * no float32 implementation can be held to 1e-4 there. */
+                if (weight > 0.0f && out != 0.0f) {
+                    const double cden = 2.0 * (double)color_sigma * (double)color_sigma;
+                    const double dden = 2.0 * (double)depth_sigma * (double)depth_sigma;
+                    const double xz = 103.97207708399179;
+                    double wa = 0.0, wt = 0.0;
+                    for (int i = -hw; i <= hw; i++)
+                        for (int j = -hw; j <= hw; j++) {
+                            int xj = x + j, yi = y + i;
+                            if (xj >= 0 && xj < width && yi >= 0 && yi < height &&
+                                depth[(size_t)yi * width + xj] > 50.0f) {
+                                double cdv = (double)color_diff3(cc, guide + ((size_t)yi * width + xj) * 3);
+                                double f = 1.0;
+                                float sv = spatial[(i + hw) * window_size + (j + hw)];
+                                if (sv != 0.0f) f *= (double)sv;
+                                if (color_sigma != 0.0f && cdv / cden < xz) f *= exp(-cdv / cden);
+                                wa += (double)depth[(size_t)yi * width + xj] * f;
+                                wt += f;
+                            }
+                        }
+                    wa /= wt;
+                    double nu = 0.0, de = 0.0;
+                    for (int i = -hw; i <= hw; i++)
+                        for (int j = -hw; j <= hw; j++) {
+                            int xj = x + j, yi = y + i;
+                            if (xj >= 0 && xj < width && yi >= 0 && yi < height &&
+                                depth[(size_t)yi * width + xj] > 50.0f) {
+                                double dq = (double)depth[(size_t)yi * width + xj];
+                                double cdv = (double)color_diff3(cc, guide + ((size_t)yi * width + xj) * 3);
+                                double f = 1.0;
+                                float sv = spatial[(i + hw) * window_size + (j + hw)];
+                                if (sv != 0.0f) f *= (double)sv;
+                                if (color_sigma != 0.0f && cdv / cden < xz) f *= exp(-cdv / cden);
+                                double xd = (dq - wa) * (dq - wa) / dden;
+                                if (depth_sigma != 0.0f && xd < xz) f *= exp(-xd);
+                                nu += dq * f;
+                                de += f;
+                            }
+                        }
+                    if (de > 0.0 && fabs((double)out - nu / de) > 2e-5 * fabs(nu / de)) flag |= 4;
+                }
+                ill[(size_t)y * width + x] = flag;
+            }
         }
     }
 }

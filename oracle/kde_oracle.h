@@ -47,8 +47,12 @@ void okde_cv_bilateral_8uc3(const uint8_t* src, int width, int height, size_t sr
                             uint8_t* dst, size_t dst_step);
 
 /* K1: joint_bilateral_filtering, JointBilateralFilter/JointBilateralFilter.cu:4-83.
- * ill (optional, may be NULL): per-pixel flag set when the final denominator is positive but
- * < 1e-30 (every surviving weight is a denormal-scale number: result is ill-conditioned). */
+ * ill (optional, may be NULL): per-pixel flags marking outputs that are not well defined at the
+ * 1e-4 level: bit 0 = final denominator < 1e-30 (every surviving weight is denormal-scale);
+ * bit 1 = some tap's depth term sits within 1e-4 (relative) of the expf-underflow point, where the
+ * reference's "factor == 0 -> skipped" rule (Q1) makes the output discontinuous in w_average;
+ * bit 2 = the float32 result differs from a binary64 evaluation of the same formula by > 2e-5
+ * (the pixel amplifies last-ulp roundings of w_average by more than 200x). */
 void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* guide_bgr,
                      const float* spatial, int window, float color_sigma, float depth_sigma,
                      float* filtered, uint8_t* ill);

@@ -57,7 +57,7 @@ def main():
     full["depth_crc32"] = crc(depth)
     full["smooth_crc32"] = crc(smooth)
     full["jbf"] = stats(filt)
-    full["jbf_ill"] = int(ill.sum())
+    full["jbf_ill"] = int((ill & 1).sum())
     full["points"] = stats(pts.view(np.float32))
     full["sp_labels_crc32"] = crc(rg["sp_labels"])
     full["dasp_labels_crc32"] = crc(rg["dasp_labels"])
@@ -72,9 +72,9 @@ def main():
     Kc = synth.intrinsics(64, 48)
     g = {"bgr": cb, "depth": cd}
     g["k0_smooth"] = O.cv_bilateral(cb, 5, 30.0, 30.0)
-    g["k1_jbf_ref_params"] = O.jbf_kernel(cd, g["k0_smooth"])
-    g["jbf_process"] = O.jbf_process(cd, cb)
-    g["k1_jbf_w11_s3_c7p65"] = O.jbf_kernel(cd, cb, 11, 3.0, 7.65, 20.0)
+    g["k1_jbf_ref_params"], g["k1_jbf_ref_params_ill"] = O.jbf_kernel(cd, g["k0_smooth"], return_ill=True)
+    g["jbf_process"], _, g["jbf_process_ill"] = O.jbf_process(cd, cb, return_all=True)
+    g["k1_jbf_w11_s3_c7p65"], g["k1_jbf_w11_s3_c7p65_ill"] = O.jbf_kernel(cd, cb, 11, 3.0, 7.65, 20.0, return_ill=True)
     g["mrf"] = O.mrf_kernel(cd, cb)
     cp = O.p2r_depth(cd, Kc)
     g["k2_points"] = cp.view(np.float32).reshape(48, 64, 3)

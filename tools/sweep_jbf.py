@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""LDS-tile / pixels-per-thread sweep of the K1 variants (BASELINE config 3): times every kernel variant
+that implements the requested window on a resident batch and prints one JSON line per variant."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--window", type=int, default=19)
+    ap.add_argument("--spatial-sigma", type=float, default=3.0)
+    ap.add_argument("--color-sigma", type=float, default=7.65)
+    ap.add_argument("--depth-sigma", type=float, default=20.0)
+    ap.add_argument("--iters", type=int, default=10)
+    a = ap.parse_args()
+    import torch
+    from kinectdepthmapenhancement_amd import filters, synth
+    bgr, depth = synth.make_batch(500, min(a.frames, 2), a.width, a.height)
+    reps = -(-a.frames // bgr.shape[0])
+    color = torch.from_numpy(np.tile(bgr, (reps, 1, 1, 1))[:a.frames]).cuda()
+    d = torch.from_numpy(np.tile(depth, (reps, 1, 1))[:a.frames]).cuda()
+    out = torch.empty_like(d)
+    p = filters.JointBilateralFilter.default_params()
+    p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma, p.presmooth = a.window, a.spatial_sigma, a.color_sigma, a.depth_sigma, 0
+    jbf = filters.JointBilateralFilter(a.width, a.height, p, max_batch=a.frames)
+    px = a.frames * a.width * a.height
+    for v, name in enumerate(filters.JointBilateralFilter.variants()):
+        if v != 0 and int(name.split("-")[0][1:]) != a.window:
+            continue
+        jbf.set_variant(v)
+        for _ in range(2):
+            jbf.filter_batch(d, color, out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            jbf.filter_batch(d, color, out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        print(json.dumps({"variant": name, "window": a.window, "size": f"{a.width}x{a.height}x{a.frames}", "ms": round(ms, 4),
+                          "mpix_s": round(px / ms / 1e3, 1), "hbm_frac": round(11.0 * px / (ms * 1e-3) / 8e12, 5)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
