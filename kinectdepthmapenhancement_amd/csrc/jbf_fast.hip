@@ -36,9 +36,11 @@ struct FastArgs {
     float sd;        // sqrt(log2(e) / (2 sigma_d^2))
     float t_skip;    // depth factor skipped when |d_q - avg| * sd >= t_skip
     int cd_skip;     // colour factor skipped when cd >= cd_skip
-    float ls[361];   // log2 of the spatial table (zeros of the table -> factor skipped -> log2 = 0)
-    float lsx[31];   // separable form, log2 domain: ls[i][j] = lsx[i] + lsx[j] (only when no table entry is 0)
-    float sy[31];    // 2^lsx[i]: per-row linear factor applied to the row's partial sums
+    int vec4;        // width % 4 == 0 and 16-byte aligned frames: the packed kernels load 4-pixel groups
+    // log2 of the spatial table (zeros of the table -> factor skipped -> log2 = 0).  Scalar kernels read
+    // tab[i*WIN + j]; packed kernels read the pair (ls[i][j of p0], ls[i][j of p1]) of unit u at
+    // tab[(i*WIN + u)*2 .. +1], so the addend of the argument fma is one aligned SGPR pair.
+    __attribute__((aligned(8))) float tab[722];
 };
 
 __device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c)
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_fast_kernel(const FastArgs a)
         }
 #pragma unroll
         for (int j = 0; j < WIN; j++) {
-            const float ls = a.ls[i * WIN + j];
+            const float ls = a.tab[i * WIN + j];
 #pragma unroll
             for (int k = 0; k < PX; k++) {
                 const float a1 = arg1_of(cr[j + k], nr[j + k], k, ls);
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_fast_kernel(const FastArgs a)
         }
 #pragma unroll
         for (int j = 0; j < WIN; j++) {
-            const float ls = CACHE ? 0.0f : a.ls[i * WIN + j];
+            const float ls = CACHE ? 0.0f : a.tab[i * WIN + j];
 #pragma unroll
             for (int k = 0; k < PX; k++) {
                 const float a1 = CACHE ? arg[(i * WIN + j) * PX + k] : arg1_of(cr[j + k], nr[j + k], k, ls);
@@ -221,8 +223,8 @@ __global__ __launch_bounds__(BX* BY) void jbf_fast_kernel(const FastArgs a)
 //    straight  (j even):  p0 tap j   = lo(m),  p1 tap j     = hi(m)
 //    swapped   (j odd>1): p0 tap j   = hi(m),  p1 tap j - 2 = lo(m)      (op_sel swap, no data movement)
 //    leftover:            p0 tap 1   = hi(m0), p1 tap WIN-2 = lo(m1)     (one v_pk_mov_b32)
-// The spatial weight is applied separably: lsx[j] rides in the per-unit constant of the argument fma and
-// the row factor sy[i] scales the row's partial sums once per row, so no per-tap spatial operation is left.
+// The spatial weight costs nothing per tap: log2(S[i][j]) of the unit's two taps is the (SGPR-pair) addend of
+// the argument fma.
 // Per tap: pass 1 = v_dot4 + v_lshl_add + v_exp (8 cycles) + 2 packed ops (4 per unit: add, fma, fma, add);
 // pass 2 = v_cmp + v_cndmask + v_exp + 2.5 packed ops (5 per unit: add, mul, fma, fma, add).
 // ---------------------------------------------------------------------------------------------------
@@ -232,17 +234,26 @@ typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 bcast(float v) { return f2{v, v}; }
 
-template <int WIN, int NP, int BX, int BY, bool CACHE, bool CSKIP>
+template <int WIN, int NP, int BX, int BY, bool CACHE, bool CSKIP, bool VL>
 __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
 {
     constexpr int R = WIN / 2;
     constexpr int PX = 2 * NP;
     constexpr int NT = BX * BY;
     constexpr int TW = BX * PX, TH = BY;
-    constexpr int LW = TW + 2 * R, LH = TH + 2 * R;
-    constexpr int P = LW;                 // even: TW and 2R are even
-    constexpr int SEGP = NP + R;          // aligned pairs in the row segment of a thread
+    constexpr int LH = TH + 2 * R;
+    // LDS column 0 is image column o = xb0 - RA with xb0 = (tile index)*TW - S1.  S1 shifts the tiles one
+    // column left when R is odd so that a thread's first window column (xb - R) is even (pairs stay aligned),
+    // and RA >= R is chosen so that o is a multiple of 4: the loader then moves 4-pixel groups with
+    // 16-byte depth loads and 12-byte colour loads that are aligned in the image.
+    // VL = false keeps the plain geometry (RA = R, one pixel per loader iteration) for A/B measurements.
+    constexpr int S1 = VL ? (R & 1) : 0;
+    constexpr int RA = !VL ? R : (S1 ? ((R - 3 + 3) / 4 * 4 + 3) : ((R + 3) / 4 * 4));
+    constexpr int P = VL ? (RA + TW + R + 3) / 4 * 4 : (TW + 2 * R);   // row pitch in dwords
+    constexpr int G = P / 4;                          // 4-pixel groups per row
+    constexpr int SEGP = NP + R;                      // aligned pairs in the row segment of a thread
     constexpr int HALF = (WIN - 1) / 2;
+    static_assert(RA >= R && (RA - R) % 2 == 0 && P % 2 == 0 && (!VL || ((RA + S1) % 4 == 0 && TW % 4 == 0)), "tile geometry");
     __shared__ __attribute__((aligned(16))) float s_d[LH * P];
     __shared__ __attribute__((aligned(16))) uint32_t s_c[LH * P];
     __shared__ __attribute__((aligned(16))) uint32_t s_n[LH * P];
@@ -256,38 +267,77 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     const unsigned frame_i = id / tiles;
     const unsigned tile = id - frame_i * tiles;
     const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
-    const int x0 = txi * TW, y0 = tyi * TH;
+    const int x0 = txi * TW - S1, y0 = tyi * TH;
+    const int o = x0 - RA;
 
     const size_t frame = (size_t)frame_i * a.width * a.height;
     const float* __restrict__ depth = a.depth + frame;
     const uint8_t* __restrict__ guide = a.guide + frame * 3;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < LW * LH; i += NT) {
-        const int ly = i / LW, lx = i - ly * LW;
-        const int gx = x0 + lx - R, gy = y0 + ly - R;
-        float d = 0.0f;
-        uint32_t c = 0;
-        if (gx >= 0 && gx < a.width && gy >= 0 && gy < a.height) {
-            const size_t q = (size_t)gy * a.width + gx;
-            d = depth[q];
-            const uint8_t* p = guide + q * 3;
-            c = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    if (!VL) {
+        for (int i = tid; i < P * LH; i += NT) {
+            const int ly = i / P, lx = i - ly * P;
+            const int gx = o + lx, gy = y0 - R + ly;
+            float d = 0.0f;
+            uint32_t c = 0;
+            if (gx >= 0 && gx < a.width && gy >= 0 && gy < a.height) {
+                const size_t q = (size_t)gy * a.width + gx;
+                d = depth[q];
+                const uint8_t* p = guide + q * 3;
+                c = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+            }
+            const bool valid = d > 50.0f;
+            s_d[i] = valid ? d : 0.0f;
+            s_c[i] = c;
+            s_n[i] = valid ? (kMagic + kOff) - dot4(c, c, 0) : kInvalidBias;
         }
-        const bool valid = d > 50.0f;
-        s_d[ly * P + lx] = valid ? d : 0.0f;
-        s_c[ly * P + lx] = c;
-        s_n[ly * P + lx] = valid ? (kMagic + kOff) - dot4(c, c, 0) : kInvalidBias;
+    }
+    for (int g = tid; VL && g < G * LH; g += NT) {
+        const int ly = g / G, gi = g - ly * G;
+        const int gx = o + 4 * gi, gy = y0 - R + ly;
+        float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        uint32_t c[4] = {0u, 0u, 0u, 0u};
+        if (gy >= 0 && gy < a.height) {
+            const size_t q = (size_t)gy * a.width + gx;
+            if (a.vec4 && gx >= 0 && gx + 3 < a.width) {
+                const float4 dv = *reinterpret_cast<const float4*>(depth + q);
+                const uint32_t* cp = reinterpret_cast<const uint32_t*>(guide + q * 3);
+                const uint32_t w0 = cp[0], w1 = cp[1], w2 = cp[2];      // 4 packed BGR pixels
+                d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
+                c[0] = w0 & 0xffffffu;
+                c[1] = (w0 >> 24) | ((w1 & 0xffffu) << 8);
+                c[2] = (w1 >> 16) | ((w2 & 0xffu) << 16);
+                c[3] = w2 >> 8;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (gx + k >= 0 && gx + k < a.width) {
+                        d[k] = depth[q + k];
+                        const uint8_t* p = guide + (q + k) * 3;
+                        c[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+                    }
+                }
+            }
+        }
+        uint32_t nn[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool valid = d[k] > 50.0f;
+            d[k] = valid ? d[k] : 0.0f;
+            nn[k] = valid ? (kMagic + kOff) - dot4(c[k], c[k], 0) : kInvalidBias;
+        }
+        const int li = ly * P + 4 * gi;
+        *reinterpret_cast<float4*>(&s_d[li]) = make_float4(d[0], d[1], d[2], d[3]);
+        *reinterpret_cast<uint4*>(&s_c[li]) = make_uint4(c[0], c[1], c[2], c[3]);
+        *reinterpret_cast<uint4*>(&s_n[li]) = make_uint4(nn[0], nn[1], nn[2], nn[3]);
     }
     __syncthreads();
 
     const int tx = tid % BX, ty = tid / BX;
     const int xb = x0 + tx * PX, y = y0 + ty;
     if (xb >= a.width || y >= a.height) return;
-
-    // tap indices (j of p0, j of p1) of unit u
-    auto unit_j0 = [](int u) { return u <= HALF ? 2 * u : (u < WIN - 1 ? 2 * (u - HALF) + 1 : 1); };
-    auto unit_j1 = [](int u) { return u <= HALF ? 2 * u : (u < WIN - 1 ? 2 * (u - HALF) - 1 : WIN - 2); };
+    const int sx = RA - R + tx * PX;       // LDS column of this thread's first window column (even)
 
     uint32_t cc[PX], thrU[PX];
     f2 negC[NP];          // -(2^23 + 2^18 + |a|^2): F + negC = -cd exactly (integers < 2^24)
@@ -296,20 +346,22 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int k = 2 * pp + h;
-            cc[k] = s_c[(ty + R) * P + tx * PX + R + k];
+            cc[k] = s_c[(ty + R) * P + sx + R + k];
             const uint32_t na = dot4(cc[k], cc[k], 0);
             negC[pp][h] = -(kBiasF + (float)na);
             thrU[k] = CSKIP ? (kMagic + kOff) + na - (uint32_t)a.cd_skip : 0;
         }
     }
 
+    f2 kc2 = bcast(a.kc);
+    asm volatile("" : "+v"(kc2));   // keep kc in a VGPR pair: the fma's only scalar operand is then the log2(S) SGPR pair
     f2 arg[CACHE ? WIN * WIN * NP : 1];
     f2 wsum[NP], wgt[NP];
 #pragma unroll
     for (int pp = 0; pp < NP; pp++) wsum[pp] = wgt[pp] = bcast(0.0f);
 
     // argument (log2 domain, without the row factor) of S*cf for the two taps of unit u of pair pp
-    auto unit_arg = [&](const u2* cp, const u2* np, int pp, int u) -> f2 {
+    auto unit_arg = [&](const u2* cp, const u2* np, int pp, int i, int u) -> f2 {
         uint32_t c0, c1, n0, n1;
         if (u <= HALF) {                       // straight
             c0 = cp[pp + u].x; c1 = cp[pp + u].y; n0 = np[pp + u].x; n1 = np[pp + u].y;
@@ -321,10 +373,10 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         }
         const uint32_t u0 = (dot4(c0, cc[2 * pp], 0) << 1) + n0;
         const uint32_t u1 = (dot4(c1, cc[2 * pp + 1], 0) << 1) + n1;
-        // -cd exactly, then ONE rounding in the fma: a1 = lsx[j] - kc*cd  (log2 of Sx_j * cf)
+        // -cd exactly, then ONE rounding in the fma: a1 = log2(S[i][j]) - kc*cd
         const f2 ncd = f2{__uint_as_float(u0), __uint_as_float(u1)} + negC[pp];
-        const f2 lsj = f2{a.lsx[unit_j0(u)], a.lsx[unit_j1(u)]};
-        f2 a1 = pk_fma(ncd, bcast(a.kc), lsj);
+        const f2 lsj = *reinterpret_cast<const f2*>(&a.tab[(i * WIN + u) * 2]);
+        f2 a1 = pk_fma(ncd, kc2, lsj);
         if (CSKIP) {   // Q1: an underflowed colour factor is skipped (invalid codes compare above the threshold)
             a1.x = (u0 <= thrU[2 * pp]) ? lsj.x : a1.x;
             a1.y = (u1 <= thrU[2 * pp + 1]) ? lsj.y : a1.y;
@@ -340,27 +392,23 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     auto pass1_row = [&](int i) {
         f2 dp[SEGP];
         u2 cp[SEGP], np[SEGP];
-        const int rb = (ty + i) * P + tx * PX;
+        const int rb = (ty + i) * P + sx;
 #pragma unroll
         for (int m = 0; m < SEGP; m++) {
             dp[m] = *reinterpret_cast<const f2*>(&s_d[rb + 2 * m]);
             cp[m] = *reinterpret_cast<const u2*>(&s_c[rb + 2 * m]);
             np[m] = *reinterpret_cast<const u2*>(&s_n[rb + 2 * m]);
         }
-        const f2 syi = bcast(a.sy[i]);
 #pragma unroll
         for (int pp = 0; pp < NP; pp++) {
-            f2 rs = bcast(0.0f), rw = bcast(0.0f);
 #pragma unroll
             for (int u = 0; u < WIN; u++) {
-                const f2 a1 = unit_arg(cp, np, pp, u);
+                const f2 a1 = unit_arg(cp, np, pp, i, u);
                 if (CACHE) arg[(i * NP + pp) * WIN + u] = a1;
                 const f2 f = f2{__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
-                rs = pk_fma(unit_depth(dp, pp, u), f, rs);
-                rw = rw + f;
+                wsum[pp] = pk_fma(unit_depth(dp, pp, u), f, wsum[pp]);
+                wgt[pp] = wgt[pp] + f;
             }
-            wsum[pp] = pk_fma(syi, rs, wsum[pp]);
-            wgt[pp] = pk_fma(syi, rw, wgt[pp]);
         }
     };
     if (CACHE) {
@@ -374,14 +422,16 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     f2 c2[NP], num[NP], den[NP];
 #pragma unroll
     for (int pp = 0; pp < NP; pp++) {
-        c2[pp] = wsum[pp] / wgt[pp];             // window averages; wgt == 0 handled at the store
+        // window averages (wgt == 0 handled at the store); v_rcp_f32 is 1 ulp, the same order as the
+        // summation-order noise already present in wsum
+        c2[pp] = wsum[pp] * f2{__builtin_amdgcn_rcpf(wgt[pp].x), __builtin_amdgcn_rcpf(wgt[pp].y)};
         num[pp] = den[pp] = bcast(0.0f);
     }
 
     auto pass2_row = [&](int i) {
         f2 dp[SEGP];
         u2 cp[SEGP], np[SEGP];
-        const int rb = (ty + i) * P + tx * PX;
+        const int rb = (ty + i) * P + sx;
 #pragma unroll
         for (int m = 0; m < SEGP; m++) {
             dp[m] = *reinterpret_cast<const f2*>(&s_d[rb + 2 * m]);
@@ -390,24 +440,20 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
                 np[m] = *reinterpret_cast<const u2*>(&s_n[rb + 2 * m]);
             }
         }
-        const f2 syi = bcast(a.sy[i]);
 #pragma unroll
         for (int pp = 0; pp < NP; pp++) {
-            f2 rn = bcast(0.0f), rd = bcast(0.0f);
 #pragma unroll
             for (int u = 0; u < WIN; u++) {
-                const f2 a1 = CACHE ? arg[(i * NP + pp) * WIN + u] : unit_arg(cp, np, pp, u);
+                const f2 a1 = CACHE ? arg[(i * NP + pp) * WIN + u] : unit_arg(cp, np, pp, i, u);
                 const f2 dq = unit_depth(dp, pp, u);
                 const f2 t = (dq - c2[pp]) * bcast(a.sd);    // subtract first: see the scalar kernel
                 f2 a2 = pk_fma(-t, t, a1);
                 a2.x = (__builtin_fabsf(t.x) >= a.t_skip) ? a1.x : a2.x;   // Q1: underflowed depth factor skipped
                 a2.y = (__builtin_fabsf(t.y) >= a.t_skip) ? a1.y : a2.y;
                 const f2 f = f2{__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
-                rn = pk_fma(dq, f, rn);
-                rd = rd + f;
+                num[pp] = pk_fma(dq, f, num[pp]);
+                den[pp] = den[pp] + f;
             }
-            num[pp] = pk_fma(syi, rn, num[pp]);
-            den[pp] = pk_fma(syi, rd, den[pp]);
         }
     };
     if (CACHE) {
@@ -418,29 +464,29 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         for (int i = 0; i < WIN; i++) pass2_row(i);
     }
 
-    float* __restrict__ o = a.out + frame + (size_t)y * a.width + xb;
+    float* __restrict__ op = a.out + frame + (size_t)y * a.width + xb;
 #pragma unroll
     for (int pp = 0; pp < NP; pp++) {
         float r0 = 0.0f, r1 = 0.0f;
-        if (wgt[pp].x > 0.0f) r0 = (den[pp].x == 0.0f) ? 0.0f : num[pp].x / den[pp].x;
-        if (wgt[pp].y > 0.0f) r1 = (den[pp].y == 0.0f) ? 0.0f : num[pp].y / den[pp].y;
-        if (xb + 2 * pp < a.width) o[2 * pp] = r0;
-        if (xb + 2 * pp + 1 < a.width) o[2 * pp + 1] = r1;
+        if (wgt[pp].x > 0.0f) r0 = (den[pp].x == 0.0f) ? 0.0f : num[pp].x * __builtin_amdgcn_rcpf(den[pp].x);
+        if (wgt[pp].y > 0.0f) r1 = (den[pp].y == 0.0f) ? 0.0f : num[pp].y * __builtin_amdgcn_rcpf(den[pp].y);
+        if (xb + 2 * pp >= 0 && xb + 2 * pp < a.width) op[2 * pp] = r0;
+        if (xb + 2 * pp + 1 < a.width) op[2 * pp + 1] = r1;
     }
 }
 
-template <int WIN, int NP, int BX, int BY, bool CACHE>
+template <int WIN, int NP, int BX, int BY, bool CACHE, bool VL>
 int launch_pk_variant(const JbfLaunch& l, const FastArgs& fa, bool cskip, hipStream_t s)
 {
     FastArgs a = fa;
-    a.tiles_x = ceil_div(l.width, BX * NP * 2);
+    a.tiles_x = ceil_div(l.width + (VL ? ((WIN / 2) & 1) : 0), BX * NP * 2);   // VL tiles start one column early for odd radii
     a.tiles_y = ceil_div(l.height, BY);
     const long long blocks = (long long)a.tiles_x * a.tiles_y * l.n;
     if (blocks > 0x7fffffffLL) return fail(KDE_ERR_INVALID, "jbf: batch too large for one launch");
     if (cskip)
-        hipLaunchKernelGGL((jbf_pk_kernel<WIN, NP, BX, BY, CACHE, true>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
+        hipLaunchKernelGGL((jbf_pk_kernel<WIN, NP, BX, BY, CACHE, true, VL>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
     else
-        hipLaunchKernelGGL((jbf_pk_kernel<WIN, NP, BX, BY, CACHE, false>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
+        hipLaunchKernelGGL((jbf_pk_kernel<WIN, NP, BX, BY, CACHE, false, VL>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }
@@ -464,26 +510,32 @@ int launch_variant(const JbfLaunch& l, const FastArgs& fa, bool cskip, hipStream
 struct Variant {
     const char* name;
     int window;
-    bool separable_only;   // packed kernels apply the spatial weight separably: no table entry may be 0
+    bool separable_only;   // (unused: every variant takes the full table)
+    bool packed;           // packed kernels read the table as (tap of p0, tap of p1) pairs per unit
     int (*launch)(const JbfLaunch&, const FastArgs&, bool, hipStream_t);
 };
 
 // name: w<window>-<pk|sc><pixels per thread>-<threads x>x<threads y>-<c = pass-1 arguments cached in registers | r = recomputed>
 #define V(WIN, PX, BX, BY, CACHE) \
-    {"w" #WIN "-sc" #PX "-" #BX "x" #BY "-" #CACHE, WIN, false, &launch_variant<WIN, PX, BX, BY, CACHE>}
+    {"w" #WIN "-sc" #PX "-" #BX "x" #BY "-" #CACHE, WIN, false, false, &launch_variant<WIN, PX, BX, BY, CACHE>}
 #define K(WIN, NP, BX, BY, CACHE) \
-    {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE, WIN, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE>}
+    {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v4", WIN, false, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, true>}
+#define KS(WIN, NP, BX, BY, CACHE) \
+    {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v1", WIN, false, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, false>}
 const Variant kVariants[] = {
-    K(5, 1, 32, 8, true),   K(5, 2, 32, 8, true),   K(5, 1, 16, 16, true),  K(5, 1, 32, 8, false),
+    // the FIRST variant listed for a window is the built-in choice (interleaved A/B sweep on MI355X,
+    // profiles/r01_sweep_k1_variants.log); the others stay selectable for the tile sweep of BASELINE config 3
+    K(5, 1, 32, 8, true),   K(5, 1, 16, 16, true),  KS(5, 1, 16, 16, true),  K(5, 2, 32, 8, true),  K(5, 1, 32, 8, false),
     V(5, 2, 32, 8, true),   V(5, 1, 64, 4, true),
-    K(7, 1, 32, 8, true),   K(7, 1, 32, 8, false),  V(7, 1, 64, 4, true),   V(7, 2, 32, 8, false),
-    K(11, 1, 32, 8, false), K(11, 2, 32, 8, false), K(11, 1, 16, 16, false), K(11, 2, 16, 16, false),
-    V(11, 2, 16, 16, false), V(11, 1, 64, 4, false),
-    K(19, 1, 32, 8, false), K(19, 2, 32, 8, false), K(19, 1, 16, 16, false), K(19, 2, 16, 16, false),
-    V(19, 2, 16, 16, false), V(19, 1, 64, 4, false),
+    K(7, 1, 16, 16, true),  K(7, 1, 32, 8, true),   KS(7, 1, 32, 8, true),  K(7, 1, 32, 8, false),  V(7, 1, 64, 4, true),
+    KS(11, 2, 16, 16, false), K(11, 2, 16, 16, false), KS(11, 1, 16, 16, false), K(11, 1, 16, 16, false), K(11, 1, 32, 8, false),
+    V(11, 2, 16, 16, false),
+    KS(19, 2, 16, 16, false), K(19, 2, 16, 16, false), KS(19, 1, 16, 16, false), K(19, 1, 16, 16, false), K(19, 1, 32, 8, false),
+    V(19, 2, 16, 16, false),
 };
 #undef V
 #undef K
+#undef KS
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 }  // namespace
@@ -535,16 +587,24 @@ int launch_jbf_fast(const JbfLaunch& l, int variant, const float* table_host, hi
     a.sd = (float)std::sqrt(log2e / (double)l.depth_den);
     a.t_skip = std::isinf(l.d2_skip) ? INFINITY : (float)(std::sqrt((double)l.d2_skip) * std::sqrt(log2e / (double)l.depth_den));
     a.cd_skip = l.cd_skip;
-    for (int i = 0; i < l.window * l.window; i++) {
-        const float sv = table_host[i];
-        a.ls[i] = (sv == 0.0f) ? 0.0f : (float)std::log2((double)sv);   // S == 0 -> factor skipped
-    }
-    // separable form of the spatial table: S[i][j] = exp(-((j-r)^2 + (i-r)^2) / (2 sigma^2))
-    for (int j = 0; j < l.window; j++) {
-        const double dj = (double)(j - l.window / 2);
-        const double lg = -(dj * dj) / (2.0 * (double)l.spatial_sigma * (double)l.spatial_sigma) * log2e;
-        a.lsx[j] = (float)lg;
-        a.sy[j] = (float)std::exp2(lg);
+    a.vec4 = (l.width % 4 == 0) && ((reinterpret_cast<uintptr_t>(l.depth) & 15u) == 0) &&
+             ((reinterpret_cast<uintptr_t>(l.guide) & 3u) == 0);
+    const int W = l.window, HALF = (W - 1) / 2;
+    auto lg = [&](int i, int j) {
+        const float sv = table_host[i * W + j];
+        return (sv == 0.0f) ? 0.0f : (float)std::log2((double)sv);   // S == 0 -> factor skipped
+    };
+    if (!kVariants[variant].packed) {
+        for (int i = 0; i < W; i++)
+            for (int j = 0; j < W; j++) a.tab[i * W + j] = lg(i, j);
+    } else {
+        for (int i = 0; i < W; i++)
+            for (int u = 0; u < W; u++) {   // unit -> (tap of p0, tap of p1): see jbf_pk_kernel
+                const int j0 = u <= HALF ? 2 * u : (u < W - 1 ? 2 * (u - HALF) + 1 : 1);
+                const int j1 = u <= HALF ? 2 * u : (u < W - 1 ? 2 * (u - HALF) - 1 : W - 2);
+                a.tab[(i * W + u) * 2] = lg(i, j0);
+                a.tab[(i * W + u) * 2 + 1] = lg(i, j1);
+            }
     }
     const bool cskip = l.cd_skip <= 195075;
     return kVariants[variant].launch(l, a, cskip, s);

@@ -133,70 +133,124 @@ __global__ __launch_bounds__(kThreads) void jbf_generic_kernel(JbfDev a)
 }
 
 // --------------------------------------------------------------------------------------------
-// K0 — cv::gpu::bilateralFilter on packed 8UC3.  The weight exp(space2*ss + n1^2*sc) depends only
-// on (space2, n1) with n1 = L1 colour distance in [0,765]; the host tabulates it with the same
-// float expression the CPU restatement uses, so the u8 result is bit-identical by construction.
+// K0 — cv::gpu::bilateralFilter on packed 8UC3 (OpenCV 2.4.3 gpu; call site JointBilateralFilter.cu:285).
+// The weight exp(space2*ss + n1^2*sc) depends only on (space2, n1) with n1 = L1 colour distance in
+// [0,765]; the host tabulates it with the same float expression the CPU restatement uses, and the
+// accumulation order / fma / IEEE division are the same, so the u8 result is bit-identical by construction.
+//
+// Persistent workgroups: the 15 KB table is staged in LDS ONCE per workgroup, which then walks 64x16
+// tiles (4 horizontally adjacent pixels per thread; n1 by one v_sad_u8, channels by v_cvt_f32_ubyteN).
+// Reflect-101 borders are resolved while staging the tile, so the tap loop has no bounds tests.
 // --------------------------------------------------------------------------------------------
 struct PreDev {
     const uint8_t* src;
     uint8_t* dst;
     const float* lut;
-    int width, height, radius;
+    int width, height, n;
+    int tiles_x, tiles_y;
 };
 
-__global__ __launch_bounds__(kThreads) void presmooth_kernel(PreDev a)
+constexpr int kPreBX = 16, kPreBY = 16, kPrePX = 4;
+constexpr int kPreTW = kPreBX * kPrePX, kPreTH = kPreBY;
+
+template <int R>
+__global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int r = a.radius;
-    const int LW = kTileX + 2 * r, LH = kTileY + 2 * r;
-    const int lut_n = (r * r + 1) * 766;
-    float* lut = reinterpret_cast<float*>(smem);
-    uint32_t* sc = reinterpret_cast<uint32_t*>(lut + lut_n);
+    constexpr int NT = kPreBX * kPreBY;
+    constexpr int LW = kPreTW + 2 * R, LH = kPreTH + 2 * R;
+    constexpr int LUT_N = (R * R + 1) * 766;
+    constexpr int SEG = kPrePX + 2 * R;
+    __shared__ float lut[LUT_N];
+    __shared__ uint32_t sc[LH * LW];
 
-    const size_t frame = (size_t)blockIdx.z * a.width * a.height;
-    const uint8_t* __restrict__ src = a.src + frame * 3;
-    const int x0 = blockIdx.x * kTileX, y0 = blockIdx.y * kTileY;
     const int tid = threadIdx.x;
+    for (int i = tid; i < LUT_N; i += NT) lut[i] = a.lut[i];
 
-    for (int i = tid; i < lut_n; i += kThreads) lut[i] = a.lut[i];
-    for (int i = tid; i < LW * LH; i += kThreads) {
-        const int ly = i / LW, lx = i - ly * LW;
-        const int gx = reflect101(x0 + lx - r, a.width);
-        const int gy = reflect101(y0 + ly - r, a.height);
-        sc[i] = load_bgrx(src, (size_t)gy * a.width + gx);
-    }
-    __syncthreads();
+    const int tiles_per_frame = a.tiles_x * a.tiles_y;
+    const int total = tiles_per_frame * a.n;
+    const int tx = tid % kPreBX, ty = tid / kPreBX;
 
-    const int tx = tid & (kTileX - 1), ty = tid / kTileX;
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= a.width || y >= a.height) return;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int frame_i = t / tiles_per_frame;
+        const int tile = t - frame_i * tiles_per_frame;
+        const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+        const int x0 = txi * kPreTW, y0 = tyi * kPreTH;
+        const size_t frame = (size_t)frame_i * a.width * a.height;
+        const uint8_t* __restrict__ src = a.src + frame * 3;
 
-    const uint32_t cc = sc[(ty + r) * LW + tx + r];
-    const int c0 = cc & 0xff, c1 = (cc >> 8) & 0xff, c2 = (cc >> 16) & 0xff;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, sum2 = 0.0f;
-    for (int dy = -r; dy <= r; dy++) {
-        for (int dx = -r; dx <= r; dx++) {
-            const int space2 = dx * dx + dy * dy;
-            if (space2 > r * r) continue;
-            const uint32_t v = sc[(ty + r + dy) * LW + tx + r + dx];
-            const int v0 = v & 0xff, v1 = (v >> 8) & 0xff, v2 = (v >> 16) & 0xff;
-            const int n1 = abs(v0 - c0) + abs(v1 - c1) + abs(v2 - c2);
-            const float w = lut[space2 * 766 + n1];
-            s0 = s0 + w * (float)v0;
-            s1 = s1 + w * (float)v1;
-            s2 = s2 + w * (float)v2;
-            sum2 = sum2 + w;
+        __syncthreads();   // previous tile fully consumed (also orders the LUT staging before first use)
+        for (int i = tid; i < LW * LH; i += NT) {
+            const int ly = i / LW, lx = i - ly * LW;
+            const int gx = reflect101(x0 + lx - R, a.width);
+            const int gy = reflect101(y0 + ly - R, a.height);
+            sc[i] = load_bgrx(src, (size_t)gy * a.width + gx);
+        }
+        __syncthreads();
+
+        const int xb = x0 + tx * kPrePX, y = y0 + ty;
+        if (xb >= a.width || y >= a.height) continue;
+
+        uint32_t cc[kPrePX];
+        float s0[kPrePX], s1[kPrePX], s2[kPrePX], sum2[kPrePX];
+#pragma unroll
+        for (int k = 0; k < kPrePX; k++) {
+            cc[k] = sc[(ty + R) * LW + tx * kPrePX + R + k];
+            s0[k] = s1[k] = s2[k] = sum2[k] = 0.0f;
+        }
+#pragma unroll
+        for (int dy = -R; dy <= R; dy++) {
+            uint32_t v[SEG];
+            float f0[SEG], f1[SEG], f2[SEG];
+#pragma unroll
+            for (int q = 0; q < SEG; q++) {
+                v[q] = sc[(ty + R + dy) * LW + tx * kPrePX + q];
+                f0[q] = (float)(v[q] & 0xffu);
+                f1[q] = (float)((v[q] >> 8) & 0xffu);
+                f2[q] = (float)((v[q] >> 16) & 0xffu);
+            }
+#pragma unroll
+            for (int dx = -R; dx <= R; dx++) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int space2 = dx * dx + dy * dy;
+                if (space2 > R * R) continue;        // same tap order as the reference kernel: cy outer, cx inner
+#pragma unroll
+                for (int k = 0; k < kPrePX; k++) {
+                    const int q = k + R + dx;
+                    const uint32_t n1 = __builtin_amdgcn_sad_u8(v[q], cc[k], 0u);   // |db| + |dg| + |dr|
+                    const float w = lut[space2 * 766 + n1];
+                    s0[k] = __builtin_fmaf(w, f0[q], s0[k]);
+                    s1[k] = __builtin_fmaf(w, f1[q], s1[k]);
+                    s2[k] = __builtin_fmaf(w, f2[q], s2[k]);
+                    sum2[k] = sum2[k] + w;
+                }
+            }
+        }
+        auto sat = [](float x) -> uint32_t {      // saturate_cast<uchar>: round half to even, clamp
+            if (!(x > 0.0f)) return 0u;
+            if (x >= 255.0f) return 255u;
+            return (uint32_t)rintf(x);
+        };
+        uint32_t px[kPrePX];
+#pragma unroll
+        for (int k = 0; k < kPrePX; k++)
+            px[k] = sat(s0[k] / sum2[k]) | (sat(s1[k] / sum2[k]) << 8) | (sat(s2[k] / sum2[k]) << 16);
+        uint8_t* o = a.dst + (frame + (size_t)y * a.width + xb) * 3;
+        if ((a.width & 3) == 0 && xb + 3 < a.width && (reinterpret_cast<uintptr_t>(a.dst) & 3u) == 0) {
+            uint32_t* ow = reinterpret_cast<uint32_t*>(o);                  // 4 pixels = 12 bytes = 3 dwords
+            ow[0] = px[0] | (px[1] << 24);
+            ow[1] = (px[1] >> 8) | (px[2] << 16);
+            ow[2] = (px[2] >> 16) | (px[3] << 8);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPrePX; k++)
+                if (xb + k < a.width) {
+                    o[3 * k] = (uint8_t)(px[k] & 0xff);
+                    o[3 * k + 1] = (uint8_t)((px[k] >> 8) & 0xff);
+                    o[3 * k + 2] = (uint8_t)((px[k] >> 16) & 0xff);
+                }
         }
     }
-    auto sat = [](float v) -> uint8_t {
-        if (!(v > 0.0f)) return 0;
-        if (v >= 255.0f) return 255;
-        return (uint8_t)rintf(v);
-    };
-    uint8_t* o = a.dst + (frame + (size_t)y * a.width + x) * 3;
-    o[0] = sat(s0 / sum2);
-    o[1] = sat(s1 / sum2);
-    o[2] = sat(s2 / sum2);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -303,11 +357,26 @@ int launch_jbf(const JbfLaunch& a, hipStream_t s)
 
 int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
 {
-    PreDev d{a.src, a.dst, a.lut, a.width, a.height, a.radius};
-    const int r = a.radius;
-    const size_t lds = (size_t)(r * r + 1) * 766 * 4 + (size_t)(kTileX + 2 * r) * (kTileY + 2 * r) * 4;
-    dim3 grid(ceil_div(a.width, kTileX), ceil_div(a.height, kTileY), a.n);
-    hipLaunchKernelGGL(presmooth_kernel, grid, dim3(kThreads), lds, s, d);
+    PreDev d;
+    d.src = a.src;
+    d.dst = a.dst;
+    d.lut = a.lut;
+    d.width = a.width;
+    d.height = a.height;
+    d.n = a.n;
+    d.tiles_x = ceil_div(a.width, kPreTW);
+    d.tiles_y = ceil_div(a.height, kPreTH);
+    const long long total = (long long)d.tiles_x * d.tiles_y * a.n;
+    if (total > 0x7fffffffLL) return fail(KDE_ERR_INVALID, "presmooth: batch too large for one launch");
+    // persistent grid: 256 CUs x 4 workgroups (20.7 KB of LDS each), fewer if there are fewer tiles
+    const unsigned grid = (unsigned)(total < 1024 ? total : 1024);
+    switch (a.radius) {
+        case 1: hipLaunchKernelGGL(presmooth_kernel<1>, dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
+        case 2: hipLaunchKernelGGL(presmooth_kernel<2>, dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
+        case 3: hipLaunchKernelGGL(presmooth_kernel<3>, dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
+        case 4: hipLaunchKernelGGL(presmooth_kernel<4>, dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
+        default: return fail(KDE_ERR_UNSUPPORTED, "presmooth: radius %d not built", a.radius);
+    }
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }

@@ -119,9 +119,11 @@ void okde_cv_bilateral_8uc3(const uint8_t* src, int width, int height, size_t sr
                     const float v0 = (float)v[0], v1 = (float)v[1], v2 = (float)v[2];
                     float n1 = fabsf(v0 - c0) + fabsf(v1 - c1) + fabsf(v2 - c2);
                     float weight = expf(space2 * ss + (n1 * n1) * sc);
-                    s0 = s0 + weight * v0;
-                    s1 = s1 + weight * v1;
-                    s2 = s2 + weight * v2;
+                    /* "sum1 = sum1 + weight * value": nvcc contracts this to an FMA (-fmad=true is its
+                     * default and the reference build does not turn it off), so the restatement uses fmaf */
+                    s0 = fmaf(weight, v0, s0);
+                    s1 = fmaf(weight, v1, s1);
+                    s2 = fmaf(weight, v2, s2);
                     sum2 = sum2 + weight;
                 }
             }

@@ -88,9 +88,9 @@ def jbf_kernel(depth, guide, window=5, spatial_sigma=70.0, color_sigma=50.0, dep
     h, w = depth.shape
     tab = spatial_table(window, spatial_sigma)
     out = np.empty((h, w), np.float32)
-    ill = np.zeros((h, w), np.uint8)
+    ill = np.zeros((h, w), np.uint8) if return_ill else None
     lib().okde_jbf_kernel(w, h, _p(depth), _p(guide), _p(tab), window, C.c_float(color_sigma),
-                          C.c_float(depth_sigma), _p(out), _p(ill))
+                          C.c_float(depth_sigma), _p(out), _p(ill) if return_ill else None)
     return (out, ill) if return_ill else out
 
 
@@ -101,11 +101,11 @@ def jbf_process(depth, bgr, window=5, spatial_sigma=70.0, color_sigma=50.0, dept
     h, w = depth.shape
     out = np.empty((h, w), np.float32)
     smooth = np.empty((h, w, 3), np.uint8)
-    ill = np.zeros((h, w), np.uint8)
+    ill = np.zeros((h, w), np.uint8) if return_all else None    # the conditioning probe only runs on request
     ks, sc, ss = presmooth if presmooth is not None else (-100000, 0.0, 0.0)
     lib().okde_jbf_process(w, h, _p(depth), _p(bgr), window, C.c_float(spatial_sigma),
                            C.c_float(color_sigma), C.c_float(depth_sigma), ks, C.c_float(sc),
-                           C.c_float(ss), _p(smooth), _p(out), _p(ill))
+                           C.c_float(ss), _p(smooth), _p(out), _p(ill) if return_all else None)
     return (out, smooth, ill) if return_all else out
 
 

@@ -20,7 +20,9 @@ def main():
     ap.add_argument("--spatial-sigma", type=float, default=3.0)
     ap.add_argument("--color-sigma", type=float, default=7.65)
     ap.add_argument("--depth-sigma", type=float, default=20.0)
-    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--with-generic", action="store_true")
     a = ap.parse_args()
     import torch
     from kinectdepthmapenhancement_amd import filters, synth
@@ -33,21 +35,26 @@ def main():
     p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma, p.presmooth = a.window, a.spatial_sigma, a.color_sigma, a.depth_sigma, 0
     jbf = filters.JointBilateralFilter(a.width, a.height, p, max_batch=a.frames)
     px = a.frames * a.width * a.height
-    for v, name in enumerate(filters.JointBilateralFilter.variants()):
-        if v != 0 and int(name.split("-")[0][1:]) != a.window:
-            continue
-        jbf.set_variant(v)
-        for _ in range(2):
+    names = filters.JointBilateralFilter.variants()
+    todo = [v for v, nm in enumerate(names) if v == 0 and a.with_generic or v != 0 and int(nm.split("-")[0][1:]) == a.window]
+    times = {v: [] for v in todo}
+    for rnd in range(a.rounds + 1):            # interleaved rounds in one process; round 0 is warm-up
+        for v in todo:
+            jbf.set_variant(v)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             jbf.filter_batch(d, color, out)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.iters):
-            jbf.filter_batch(d, color, out)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / a.iters
-        print(json.dumps({"variant": name, "window": a.window, "size": f"{a.width}x{a.height}x{a.frames}", "ms": round(ms, 4),
-                          "mpix_s": round(px / ms / 1e3, 1), "hbm_frac": round(11.0 * px / (ms * 1e-3) / 8e12, 5)}), flush=True)
+            e0.record()
+            for _ in range(a.iters):
+                jbf.filter_batch(d, color, out)
+            e1.record()
+            torch.cuda.synchronize()
+            if rnd:
+                times[v].append(e0.elapsed_time(e1) / a.iters)
+    for v in todo:
+        ms = float(np.median(times[v]))
+        print(json.dumps({"variant": names[v], "window": a.window, "size": f"{a.width}x{a.height}x{a.frames}",
+                          "ms_median": round(ms, 4), "ms_min": round(min(times[v]), 4), "mpix_s": round(px / ms / 1e3, 1),
+                          "hbm_frac": round(11.0 * px / (ms * 1e-3) / 8e12, 5)}), flush=True)
 
 
 if __name__ == "__main__":
