@@ -1,0 +1,44 @@
+"""The header-only C++ classes (include/kde/kde.hpp) replaying the reference's main.cpp sequence
+(examples/main_replay.cpp), checked against the oracle.  This is the drop-in boundary exercised from
+the reference's own language."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_depth_close
+
+pytestmark = pytest.mark.gpu
+
+
+def test_main_replay_matches_oracle(torch_cuda, oracle, synth, color_fixture, tmp_path):
+    exe = os.path.join(ROOT, "examples", "main_replay")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    _, depth, truth = synth.make_frame(1, 640, 480, clean=True)
+    (tmp_path / "color.bgr").write_bytes(color_fixture.tobytes())
+    (tmp_path / "depth.f32").write_bytes(depth.tobytes())
+    (tmp_path / "avg.f32").write_bytes(truth.tobytes())
+    prefix = str(tmp_path / "out_")
+    res = subprocess.run([exe, "640", "480", str(tmp_path / "color.bgr"), str(tmp_path / "depth.f32"),
+                          str(tmp_path / "avg.f32"), prefix], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    lines = {l.split()[0]: (float(l.split()[1]), int(l.split()[2])) for l in res.stdout.strip().splitlines()}
+    K = synth.intrinsics(640, 480)
+    tpts = oracle.p2r_depth(truth, K)
+
+    def load(name):
+        return np.fromfile(prefix + name + ".f32", np.float32).reshape(480, 640)
+
+    jbf_ref, _, ill = oracle.jbf_process(depth, color_fixture, return_all=True)
+    assert_depth_close(load("jbf"), jbf_ref, 1e-4, ill=ill, what="C++ JBF")
+    assert_depth_close(load("mrf"), oracle.mrf_kernel(depth, color_fixture), 1e-4, what="C++ MRF")
+    rg = oracle.rgbf_process(depth, oracle.p2r_depth(depth, K), color_fixture, 15, 20, K)
+    assert_depth_close(load("rgbf"), rg["refined_depth"], 1e-4, what="C++ RGBF")
+    # the reference's only quality metric (main.cpp:220-308): mean 3-D error vs the averaged-depth cloud
+    for name, d in (("input", depth), ("jbf", jbf_ref), ("rgbf", rg["refined_depth"])):
+        e, n = oracle.mean_3d_error(oracle.p2r_depth(d, K), tpts)
+        assert lines[name][1] == n or abs(lines[name][1] - n) <= 3
+        assert abs(lines[name][0] - e) <= 2e-3 * max(e, 1e-6), (name, lines[name], e)
+    assert lines["jbf"][0] < lines["input"][0]          # the filter actually reduces the error
