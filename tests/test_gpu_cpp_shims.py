@@ -41,4 +41,5 @@ def test_main_replay_matches_oracle(torch_cuda, oracle, synth, color_fixture, tm
         e, n = oracle.mean_3d_error(oracle.p2r_depth(d, K), tpts)
         assert lines[name][1] == n or abs(lines[name][1] - n) <= 3
         assert abs(lines[name][0] - e) <= 2e-3 * max(e, 1e-6), (name, lines[name], e)
-    assert lines["jbf"][0] < lines["input"][0]          # the filter actually reduces the error
+    # (no "the filter reduces the error" check: with the reference's constants the Q1 rule gives far depth
+    #  outliers full weight, so JBF smears depth edges and its mean 3-D error exceeds the input's)
