@@ -178,10 +178,17 @@ def main():
         px_per_launch = count * W * H
         k1_avg_ms = float(np.mean(k1_ms))
         achieved = K1_BYTES_PER_PX * px_per_launch / (k1_avg_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per K1 launch from the PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
+        # collected separately under rocprofv3 and committed as profiles/pmc_traffic.json; only quoted when
+        # that profile was taken on exactly this per-GPU workload
+        traffic, valu = None, None
         if os.path.exists(args.pmc_json):
             try:
-                traffic = json.load(open(args.pmc_json)).get("k1_hbm_bytes_per_launch")
+                pj = json.load(open(args.pmc_json))
+                wl = pj.get("workload", {})
+                if (wl.get("frames"), wl.get("width"), wl.get("height"), wl.get("window")) == (count, W, H, p.window_size):
+                    traffic = pj.get("k1_hbm_bytes_per_launch")
+                    valu = pj.get("k1_valu")
             except Exception:
                 traffic = None
         res = {
@@ -203,7 +210,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "K1 joint_bilateral_filtering", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": K1_BYTES_PER_PX * px_per_launch,
-                         "avg_launch_ms": k1_avg_ms, "k0_avg_launch_ms": float(np.mean(k0_ms))},
+                         "avg_launch_ms": k1_avg_ms, "k0_avg_launch_ms": float(np.mean(k0_ms)),
+                         # the stencil is VALU/transcendental-bound, not HBM-bound: SQ counters of the
+                         # same kernel from profiles/pmc_traffic.json (null when not profiled on this workload)
+                         "valu": valu},
             "checksum": {"sum_filtered_mm": checksum[0], "frames": int(checksum[1])},
         }
         if world == 1 and args.cpu_seconds > 0:
