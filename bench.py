@@ -131,6 +131,10 @@ def cpu_baseline(args, synth, seconds):
 
 def main():
     args = parse()
+    # RCCL prints its version banner / warnings on the C-level stdout: keep the real stdout for the ONE JSON
+    # line of the contract and send everything else that writes to fd 1 to stderr
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from kinectdepthmapenhancement_amd import filters, sharding, synth
@@ -143,10 +147,12 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"WORLD_SIZE={world} != --gpus {args.gpus}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also for N = 1: same code path)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
-    barrier = dist.barrier if world > 1 else (lambda: None)
+    barrier = dist.barrier if use_dist else (lambda: None)
 
     # ---- parameter block: rank 0 decides, everyone receives the same bytes --------------------------
     p = filters.JointBilateralFilter.default_params()
@@ -220,8 +226,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(args, synth, args.cpu_seconds)
         if world == 1 and not args.no_extra:
             res["also"] = side_measurements(torch, filters, synth, args)
-        print(json.dumps(res), flush=True)
-    if world > 1:
+        print(json.dumps(res), file=real_stdout, flush=True)
+    if use_dist:
         dist.destroy_process_group()
 
 
