@@ -551,6 +551,10 @@ struct kde_dasp {
     DevBuf<kde_float3> centers;          // superpixelCenters_Device
     DevBuf<float> intr;                  // intrinsicDevice
     PinnedBuf<int32_t> labels_host;      // Labels_Host
+    // Set by the pipeline objects (RGBF / SPDSR) for their PRIVATE segmenters: the analyzeClusters that
+    // follows the last calculateLD only refreshes mean/centres, which nothing reads before the next
+    // Segmentation re-samples them (DepthAdaptiveSuperpixel.cu:576-586) and which the pipelines do not expose.
+    bool skip_trailing_analyze = false;
 };
 
 extern "C" int kde_dasp_create(kde_dasp** out, int width, int height)
@@ -615,6 +619,7 @@ extern "C" int kde_dasp_segmentation(kde_dasp* h, const uint8_t* bgr_dev, const 
     for (int i = 0; i < iteration; i++) {
         KDE_TRY(launch_dasp_calc_ld(h->g, bgr_dev, points_dev, h->ld.p, h->mean.p, h->centers.p, h->labels.p,
                                     color_sigma, spatial_sigma, depth_sigma, s));
+        if (h->skip_trailing_analyze && i == iteration - 1) break;
         KDE_TRY(launch_dasp_analyze(h->g, bgr_dev, points_dev, h->ld.p, h->mean.p, h->centers.p, h->intr.p, s));
     }
     return KDE_OK;
@@ -789,6 +794,7 @@ struct Pipeline {
         height = h;
         KDE_TRY(kde_dasp_create(&DASP, w, h));
         KDE_TRY(kde_dasp_create(&SP, w, h));
+        DASP->skip_trailing_analyze = SP->skip_trailing_analyze = true;
         KDE_TRY(kde_ers_create(&ERS, w, h));
         return KDE_OK;
     }

@@ -58,32 +58,53 @@ __device__ __forceinline__ void p2r_one(const Camera& c, int interp, unsigned x,
     r[2] = z;
 }
 
+// A thread owns 4 pixels = 48 B of packed float3 output, which it could only store as three 16-byte
+// pieces 48 B apart.  Each wave therefore passes its 3 KB through LDS once, so that every global store
+// (and, for the float3 -> float3 maps, every load) instruction moves 64 consecutive float4 = 1 KB.
+// LDS instructions of one wave execute in issue order, so a wave-level compiler barrier is all that is
+// needed between the write and the transposed read.
+__device__ __forceinline__ void wave_exchange_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
 __global__ __launch_bounds__(kThreads) void p2r_depth_kernel(Camera c, const float* __restrict__ depth_all,
                                                             float* __restrict__ out_all, int interp)
 {
+    __shared__ float4 xch[kThreads / 64][3 * 64];
     const unsigned frame_px = (unsigned)c.width * (unsigned)c.height;
     const unsigned row = interp ? (unsigned)c.width * 2u : (unsigned)c.width;
     const float* __restrict__ depth = depth_all + (size_t)blockIdx.y * frame_px;
     float* __restrict__ out = out_all + (size_t)blockIdx.y * frame_px * 3;
     const unsigned groups = frame_px / 4;
     const unsigned stride = gridDim.x * kThreads;
-    for (unsigned g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
-        const float4 z4 = reinterpret_cast<const float4*>(depth)[g];
-        const float z[4] = {z4.x, z4.y, z4.z, z4.w};
-        float r[12];
-        unsigned y = (g * 4) / row, x = (g * 4) - y * row;
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    float4* w = xch[wv];
+    for (unsigned g0 = blockIdx.x * kThreads + wv * 64u; g0 < groups; g0 += stride) {   // wave-uniform
+        const unsigned g = g0 + lane;
+        float r[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (g < groups) {
+            const float4 z4 = reinterpret_cast<const float4*>(depth)[g];
+            const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+            unsigned y = (g * 4) / row, x = (g * 4) - y * row;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            p2r_one(c, interp, x, y, z[k], r + 3 * k);
-            if (++x == row) {
-                x = 0;
-                ++y;
+            for (int k = 0; k < 4; k++) {
+                p2r_one(c, interp, x, y, z[k], r + 3 * k);
+                if (++x == row) {
+                    x = 0;
+                    ++y;
+                }
             }
         }
-        float4* o = reinterpret_cast<float4*>(out) + (size_t)g * 3;
-        o[0] = make_float4(r[0], r[1], r[2], r[3]);
-        o[1] = make_float4(r[4], r[5], r[6], r[7]);
-        o[2] = make_float4(r[8], r[9], r[10], r[11]);
+        w[lane * 3 + 0] = make_float4(r[0], r[1], r[2], r[3]);
+        w[lane * 3 + 1] = make_float4(r[4], r[5], r[6], r[7]);
+        w[lane * 3 + 2] = make_float4(r[8], r[9], r[10], r[11]);
+        wave_exchange_fence();
+        float4* o = reinterpret_cast<float4*>(out) + (size_t)g0 * 3;
+        const unsigned nvec = (groups - g0 < 64u ? groups - g0 : 64u) * 3u;
+#pragma unroll
+        for (unsigned j = 0; j < 3; j++) {
+            const unsigned idx = j * 64u + lane;
+            if (idx < nvec) o[idx] = w[idx];
+        }
+        wave_exchange_fence();
     }
     for (unsigned i = groups * 4 + blockIdx.x * kThreads + threadIdx.x; i < frame_px; i += stride) {
         float r[3];
@@ -94,12 +115,15 @@ __global__ __launch_bounds__(kThreads) void p2r_depth_kernel(Camera c, const flo
     }
 }
 
-// float3 -> float3 maps; 4 points (48 B) per thread as three float4.
+// float3 -> float3 maps; 4 points (48 B) per thread, loads and stores both transposed through LDS.
 __global__ __launch_bounds__(kThreads) void points_map_kernel(Camera c, size_t total, const float* __restrict__ in,
                                                              float* __restrict__ out, int to_projective)
 {
+    __shared__ float4 xch[kThreads / 64][3 * 64];
     const size_t groups = total / 4;
     const size_t stride = (size_t)gridDim.x * kThreads;
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    float4* w = xch[wv];
     auto map = [&](float& x, float& y, float& z) {
         if (!to_projective) {
             convert_ptr(x, y, z, c);          // DimensionConvertor.cu:25-33
@@ -117,16 +141,31 @@ __global__ __launch_bounds__(kThreads) void points_map_kernel(Camera c, size_t t
             }
         }
     };
-    for (size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
-        const float4* p = reinterpret_cast<const float4*>(in) + g * 3;
-        float4 a = p[0], b = p[1], d = p[2];
+    for (size_t g0 = (size_t)blockIdx.x * kThreads + wv * 64u; g0 < groups; g0 += stride) {   // wave-uniform
+        const unsigned nvec = (unsigned)(groups - g0 < 64 ? groups - g0 : 64) * 3u;
+        const float4* p = reinterpret_cast<const float4*>(in) + g0 * 3;
+#pragma unroll
+        for (unsigned j = 0; j < 3; j++) {
+            const unsigned idx = j * 64u + lane;
+            w[idx] = idx < nvec ? p[idx] : make_float4(0.f, 0.f, 1.f, 0.f);
+        }
+        wave_exchange_fence();
+        const float4 a = w[lane * 3], b = w[lane * 3 + 1], d = w[lane * 3 + 2];
         float r[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) map(r[3 * k], r[3 * k + 1], r[3 * k + 2]);
-        float4* o = reinterpret_cast<float4*>(out) + g * 3;
-        o[0] = make_float4(r[0], r[1], r[2], r[3]);
-        o[1] = make_float4(r[4], r[5], r[6], r[7]);
-        o[2] = make_float4(r[8], r[9], r[10], r[11]);
+        wave_exchange_fence();
+        w[lane * 3 + 0] = make_float4(r[0], r[1], r[2], r[3]);
+        w[lane * 3 + 1] = make_float4(r[4], r[5], r[6], r[7]);
+        w[lane * 3 + 2] = make_float4(r[8], r[9], r[10], r[11]);
+        wave_exchange_fence();
+        float4* o = reinterpret_cast<float4*>(out) + g0 * 3;
+#pragma unroll
+        for (unsigned j = 0; j < 3; j++) {
+            const unsigned idx = j * 64u + lane;
+            if (idx < nvec) o[idx] = w[idx];
+        }
+        wave_exchange_fence();
     }
     for (size_t i = groups * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += stride) {
         float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
