@@ -221,6 +221,161 @@ __global__ __launch_bounds__(kThreads) void enhance_kernel(EnhDev a)
     a.out[(size_t)y * a.width + x] = result;
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// K10, tuned form for the reference's 7x7 window.  Same semantics as enhance_kernel above, restated so
+// that no tap needs a division or an expf():
+//   * colour distance by v_dot4_u32_u8 on packed BGRX with the pre-biased -|b|^2 plane (see jbf_fast.hip);
+//     -cd is exact and stays in registers (49 values) for pass 3;
+//   * weights in the log2 domain, one v_exp_f32 per tap in passes 1 and 3;
+//   * pass 3's mutating colour sigma is cs_k = max(a, c_k) with c_k = fl(0.3 * c_{k-1}) and k the rank of the
+//     tap among the valid taps (raster order), so 1/(2 cs_k^2) = min(1/(2 a^2), 1/(2 c_k^2)): the c_k terms
+//     come from a 50-entry table built on the host with the reference's float operations (an entry is +inf
+//     where 2 c_k^2 underflows to exactly 0, which reproduces the 0/0 = NaN of Q6);
+//   * the "underflowed factor is skipped" decision is taken on the integer colour distance against
+//     max(threshold(2 a^2), threshold(2 c_k^2)), both exact (smallest cd with fl(cd/den) >= x0).
+// -------------------------------------------------------------------------------------------------
+constexpr uint32_t kMagic = 0x4B000000u, kOff = 1u << 18, kInvalidBias = 0xFF000000u;
+constexpr float kBiasF = 8388608.0f + 262144.0f;
+constexpr int32_t kInvalidLabel = (int32_t)0x80000000;
+
+struct Enh7Dev {
+    const float* rd;
+    const uint8_t* bgr;
+    const int32_t* labels;
+    float* out;
+    int width, height;
+    float kc1;        // log2(e) / (2 * ColorSigma^2): pass-1 colour term (never underflows at the built sigmas)
+    float sd;         // sqrt(log2(e) / (2 * DepthSigma^2))
+    float t_skip;     // depth factor skipped when |d_q - avg| * sd >= t_skip
+    float exp_zero;   // x0: exp(-x) == 0 in binary32 iff x >= x0
+    float ls[49];     // log2 of the spatial table
+    float tinv[50];   // [k]: log2(e) / (2 c_k^2), +inf where the denominator underflows to 0
+    float tthr[50];   // [k]: -(smallest cd with fl(cd / (2 c_k^2)) >= x0)
+};
+
+__device__ __forceinline__ uint32_t dot4u(uint32_t a, uint32_t b) { return __builtin_amdgcn_udot4(a, b, 0u, false); }
+
+__global__ __launch_bounds__(kThreads) void enhance7_kernel(const Enh7Dev a)
+{
+    constexpr int WIN = 7, R = 3;
+    constexpr int LW = kTileX + 2 * R, LH = kTileY + 2 * R;
+    __shared__ float s_d[LH * LW];
+    __shared__ uint32_t s_c[LH * LW];
+    __shared__ uint32_t s_n[LH * LW];
+    __shared__ int32_t s_l[LH * LW];
+    __shared__ float2 s_t[50];        // (tinv, tthr) per rank
+
+    const int x0 = blockIdx.x * kTileX, y0 = blockIdx.y * kTileY;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < LW * LH; i += kThreads) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gx = x0 + lx - R, gy = y0 + ly - R;
+        float d = 0.0f;
+        uint32_t c = 0;
+        int32_t l = 0;
+        if (gx >= 0 && gx < a.width && gy >= 0 && gy < a.height) {
+            const size_t q = (size_t)gy * a.width + gx;
+            d = a.rd[q];
+            c = load_bgrx(a.bgr, q);
+            l = a.labels[q];
+        }
+        const bool valid = d > 50.0f;
+        s_d[i] = valid ? d : 0.0f;
+        s_c[i] = c;
+        s_n[i] = valid ? (kMagic + kOff) - dot4u(c, c) : kInvalidBias;
+        s_l[i] = valid ? l : kInvalidLabel;
+    }
+    if (tid < 50) s_t[tid] = make_float2(a.tinv[tid], a.tthr[tid]);
+    __syncthreads();
+
+    const int tx = tid & (kTileX - 1), ty = tid / kTileX;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= a.width || y >= a.height) return;
+    const size_t p = (size_t)y * a.width + x;
+    const uint32_t cc = s_c[(ty + R) * LW + tx + R];
+    const int32_t cl = a.labels[p];                       // the centre's label counts even if its depth is invalid
+    const float negC = -(kBiasF + (float)dot4u(cc, cc));
+
+    // ---- pass 1: label-restricted weighted average (.cu:116-139) --------------------------------------
+    float ncd[WIN * WIN];
+    float wsum = 0.0f, wgt = 0.0f;
+#pragma unroll
+    for (int i = 0; i < WIN; i++)
+#pragma unroll
+        for (int j = 0; j < WIN; j++) {
+            const int li = (ty + i) * LW + tx + j;
+            const uint32_t u = (dot4u(s_c[li], cc) << 1) + s_n[li];
+            const float nc = __uint_as_float(u) + negC;                // -cd exactly (-1.7e38 for an invalid tap)
+            ncd[i * WIN + j] = nc;
+            float a1 = __builtin_fmaf(nc, a.kc1, a.ls[i * WIN + j]);
+            a1 = (s_l[li] == cl) ? a1 : -3.0e38f;                      // other label or invalid: weight exactly 0
+            const float f = __builtin_amdgcn_exp2f(a1);
+            wsum = __builtin_fmaf(s_d[li], f, wsum);
+            wgt += f;
+        }
+    float result = 0.0f;
+    if (wgt > 0.0f) {
+        const float wavg = wsum / wgt;
+        // ---- pass 2: mean absolute deviation over the same taps (.cu:143-156) ---------------------------
+        float deviation = 0.0f;
+        int count = 0;
+#pragma unroll
+        for (int i = 0; i < WIN; i++)
+#pragma unroll
+            for (int j = 0; j < WIN; j++) {
+                const int li = (ty + i) * LW + tx + j;
+                const bool m = s_l[li] == cl;
+                deviation += m ? fabsf(s_d[li] - wavg) : 0.0f;
+                count += m ? 1 : 0;
+            }
+        if (count != 0) deviation /= (float)count;
+        // .cu:171: 5.0 is a double literal, pow(float,float) is float
+        const float asig = (float)(5.0 * (double)deviation / (double)(wavg * wavg));
+        const float den_a = 2 * (asig * asig);
+        // +inf only where the reference divides by an exact 0 (0/0 = NaN, Q6); a denormal denominator still gives
+        // cd/den = 0 for cd == 0, so the scale must stay finite there (cd >= 1 is then decided by the threshold)
+        const float inv_a = den_a == 0.0f ? INFINITY : fminf(1.4426950408889634f / den_a, 3.0e38f);
+        // smallest integer cd with fl(cd / den_a) >= x0 (exact: candidate from the product, then stepped)
+        float thr_a;
+        if (den_a == 0.0f) {
+            thr_a = 1.0f;                                   // cd/0 = inf for cd >= 1; 0/0 = NaN is not ">= x0"
+        } else {
+            float c0 = ceilf(a.exp_zero * den_a);
+            c0 = fminf(fmaxf(c0, 0.0f), 400000.0f);
+            while (c0 > 0.0f && (c0 - 1.0f) / den_a >= a.exp_zero) c0 -= 1.0f;
+            while (c0 < 400000.0f && !(c0 / den_a >= a.exp_zero)) c0 += 1.0f;
+            thr_a = c0;
+        }
+        const float nthr_a = -thr_a;
+        // ---- pass 3: every valid tap, colour sigma mutating with the tap's rank (.cu:158-195) ------------
+        float num = 0.0f, den = 0.0f;
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < WIN; i++)
+#pragma unroll
+            for (int j = 0; j < WIN; j++) {
+                const int li = (ty + i) * LW + tx + j;
+                const float nc = ncd[i * WIN + j];
+                const float dq = s_d[li];
+                const bool valid = nc > -1.0e37f;
+                k += valid ? 1 : 0;
+                const float2 tk = s_t[k];
+                const float invl = fminf(inv_a, tk.x);
+                float ac = __builtin_fmaf(nc, invl, a.ls[i * WIN + j]);        // log2(S) - cd * log2(e)/(2 cs_k^2)
+                ac = (valid && nc <= fminf(nthr_a, tk.y)) ? a.ls[i * WIN + j] : ac;   // underflowed colour factor skipped
+                const float t = (dq - wavg) * a.sd;
+                float a2 = __builtin_fmaf(-t, t, ac);
+                a2 = (fabsf(t) >= a.t_skip) ? ac : a2;                            // underflowed depth factor skipped
+                const float f = __builtin_amdgcn_exp2f(a2);
+                num = __builtin_fmaf(dq, f, num);
+                den += f;
+            }
+        result = (den == 0.0f) ? 0.0f : num / den;
+    }
+    a.out[p] = result;
+}
+
 }  // namespace
 
 int launch_ers_edge_phase(int width, int height, int dir, int window, const int32_t* color_labels, const int32_t* l0,
@@ -236,9 +391,56 @@ int launch_ers_edge_phase(int width, int height, int dir, int window, const int3
 }
 
 int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr, const int32_t* labels,
-                       const float* s_eff, int window, float color_sigma, float depth_sigma, float exp_zero,
-                       float* out, hipStream_t s)
+                       const float* s_eff, const float* table_host, int window, float color_sigma, float depth_sigma,
+                       float exp_zero, float* out, hipStream_t s)
 {
+    const float cden = 2 * (color_sigma * color_sigma);
+    // tuned kernel: 7x7 window, both sigmas on, pass-1 colour factor can never underflow
+    const bool tuned = window == 7 && color_sigma != 0.0f && depth_sigma != 0.0f && !(195075.0f / cden >= exp_zero);
+    if (tuned) {
+        Enh7Dev d;
+        memset(&d, 0, sizeof(d));
+        d.rd = rd; d.bgr = bgr; d.labels = labels; d.out = out; d.width = width; d.height = height;
+        const double log2e = 1.4426950408889634;
+        d.kc1 = (float)(log2e / (double)cden);
+        const float dden = 2.0f * (depth_sigma * depth_sigma);
+        d.sd = (float)std::sqrt(log2e / (double)dden);
+        {   // smallest q with fl(q / dden) >= x0, as a bound on |d_q - avg| * sd
+            uint32_t lo = 0, hi = 0x7f800000u;
+            auto val = [](uint32_t b) { float f; memcpy(&f, &b, 4); return f; };
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                if (val(mid) / dden >= exp_zero) hi = mid; else lo = mid + 1;
+            }
+            d.t_skip = (float)(std::sqrt((double)val(lo)) * std::sqrt(log2e / (double)dden));
+        }
+        d.exp_zero = exp_zero;
+        for (int i = 0; i < 49; i++)   // S == 0 -> factor skipped -> log2 = 0
+            d.ls[i] = table_host[i] == 0.0f ? 0.0f : (float)std::log2((double)table_host[i]);
+        // rank table: c_0 = ColorSigma, c_k = c_{k-1} * 0.3f (EdgeRefinedSuperpixel.cu:172-175 while a <= 0.3 c)
+        float c = color_sigma;
+        d.tinv[0] = 1.0f;    // rank 0 = only invalid taps so far: any positive scale keeps -1.7e38 * scale at -huge
+        d.tthr[0] = 0.0f;
+        for (int k = 1; k < 50; k++) {
+            c *= 0.3f;
+            const float den = 2 * (c * c);
+            if (den == 0.0f) {
+                d.tinv[k] = INFINITY;
+                d.tthr[k] = -1.0f;
+            } else {
+                d.tinv[k] = (float)std::fmin(log2e / (double)den, 3.0e38);   // finite while den != 0 (see inv_a)
+                int lo = 0, hi = 400000;
+                while (lo < hi) {
+                    const int mid = (lo + hi) / 2;
+                    if ((float)mid / den >= exp_zero) hi = mid; else lo = mid + 1;
+                }
+                d.tthr[k] = -(float)lo;
+            }
+        }
+        hipLaunchKernelGGL(enhance7_kernel, dim3(ceil_div(width, kTileX), ceil_div(height, kTileY)), dim3(kThreads), 0, s, d);
+        KDE_HIP_TRY(hipGetLastError());
+        return KDE_OK;
+    }
     EnhDev d{rd, bgr, labels, s_eff, out, width, height, window, color_sigma, depth_sigma, exp_zero};
     const int R = window / 2;
     const size_t lds = (size_t)(kTileX + 2 * R) * (kTileY + 2 * R) * 12 + (size_t)window * window * 4;

@@ -680,6 +680,7 @@ struct kde_ers {
     PinnedBuf<int32_t> labels_host;
     PinnedBuf<float> depth_host;
     float exp_zero = 0;
+    float table_host[49];                 // SpatialFilter_Host as calcSpatialFilter computed it
 };
 
 extern "C" int kde_ers_create(kde_ers** out, int width, int height)
@@ -695,6 +696,7 @@ extern "C" int kde_ers_create(kde_ers** out, int width, int height)
     const size_t px = (size_t)width * height;
     float table[49];
     spatial_table(kde_ers::WindowSize, kde_ers::SpatialSigma, table);
+    memcpy(h->table_host, table, sizeof(table));
     for (float& v : table)
         if (v == 0.0f) v = 1.0f;
     int rc = h->s_eff.alloc(49);
@@ -726,8 +728,9 @@ extern "C" int kde_ers_edge_refining(kde_ers* h, const int32_t* color_labels_dev
     KDE_TRY(launch_ers_edge_phase(W, H, 1, kde_ers::WindowSize, color_labels_dev, h->labels_b.p, h->depth_b.p,
                                   h->labels_a.p, h->depth_a.p, s));
     // depthmap_enhancement (.cu:220-221)
-    KDE_TRY(launch_ers_enhance(W, H, h->depth_a.p, bgr_dev, h->labels_a.p, h->s_eff.p, kde_ers::WindowSize,
-                               kde_ers::ColorSigma, kde_ers::DepthSigma, h->exp_zero, h->refined_depth.p, s));
+    KDE_TRY(launch_ers_enhance(W, H, h->depth_a.p, bgr_dev, h->labels_a.p, h->s_eff.p, h->table_host,
+                               kde_ers::WindowSize, kde_ers::ColorSigma, kde_ers::DepthSigma, h->exp_zero,
+                               h->refined_depth.p, s));
     return KDE_OK;
 }
 

@@ -181,7 +181,7 @@ int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3*
 int launch_ers_edge_phase(int width, int height, int dir, int window, const int32_t* color_labels, const int32_t* l0,
                           const float* d0, int32_t* l1, float* d1, hipStream_t s);
 int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr, const int32_t* labels,
-                       const float* s_eff, int window, float color_sigma, float depth_sigma, float exp_zero,
-                       float* out, hipStream_t s);
+                       const float* s_eff, const float* table_host, int window, float color_sigma, float depth_sigma,
+                       float exp_zero, float* out, hipStream_t s);
 
 }  // namespace kde

@@ -793,6 +793,10 @@ void okde_ers_edge_refining(int width, int height, const int32_t* color_labels,
 /* ------------------------------------------------------------------------------------------
  * K10 — depthmap_enhancement, EdgeRefinedSuperpixel.cu:104-205 (D3: separate output buffer)
  * ---------------------------------------------------------------------------------------- */
+static uint8_t* g_ers_flag_sink = NULL;
+
+void okde_ers_set_flag_sink(uint8_t* sink) { g_ers_flag_sink = sink; }
+
 void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr,
                       const int32_t* refined_labels, const float* spatial, int window_size,
                       float color_sigma_in, float depth_sigma, float* out)
@@ -825,6 +829,7 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                     }
                 }
             float result = 0.0f;
+            uint8_t near_jump = 0;
             if (weight > 0.0f) {
                 w_average /= weight;
                 /* deviation — .cu:143-156 */
@@ -863,8 +868,12 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                                 float dd = rd[q] - w_average;
                                 float depth_diff = dd * dd;
                                 float depth_filter = 0.0f; /* Q3 */
-                                if (depth_sigma != 0.0f)
-                                    depth_filter = expf(-depth_diff / (2.0f * (depth_sigma * depth_sigma)));
+                                if (depth_sigma != 0.0f) {
+                                    float xarg = depth_diff / (2.0f * (depth_sigma * depth_sigma));
+                                    depth_filter = expf(-xarg);
+                                    /* same discontinuity as in K1 (Q1): flag taps sitting on the underflow jump */
+                                    if (fabsf(xarg - 103.972077f) <= 103.972077f * 1e-4f) near_jump = 1;
+                                }
                                 float filter = 1.0f;
                                 float s = spatial[(i + hw) * window_size + (j + hw)];
                                 if (s != 0.0f) filter *= s;
@@ -879,6 +888,7 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                 else result = numerator / denominator;
             }
             out[p] = result;
+            if (g_ers_flag_sink) g_ers_flag_sink[p] = near_jump ? 2 : 0;
         }
     }
 }

@@ -112,6 +112,9 @@ void okde_ers_edge_refining(int width, int height, const int32_t* color_labels,
 void okde_ers_enhance(int width, int height, const float* refined_depth_in, const uint8_t* bgr,
                       const int32_t* refined_labels, const float* spatial, int window,
                       float color_sigma, float depth_sigma, float* refined_depth_out);
+/* optional W*H byte map that okde_ers_enhance fills with 2 where a tap's depth term sits within 1e-4 of the
+ * expf-underflow jump (output discontinuous there, see okde_jbf_kernel); NULL switches it off */
+void okde_ers_set_flag_sink(uint8_t* sink);
 void okde_ers_process(int width, int height, const int32_t* color_labels, const int32_t* depth_labels,
                       const float* depth, const uint8_t* bgr,
                       int32_t* refined_labels, float* refined_depth);

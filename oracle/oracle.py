@@ -264,6 +264,21 @@ def ers_edge_refining(color_labels, depth_labels, depth, window=7):
     return labels, d
 
 
+class ers_flags:
+    """context manager: collects okde_ers_enhance's discontinuity flags for every call made inside it"""
+
+    def __init__(self, shape):
+        self.flags = np.zeros(shape, np.uint8)
+
+    def __enter__(self):
+        lib().okde_ers_set_flag_sink(_p(self.flags))
+        return self.flags
+
+    def __exit__(self, *exc):
+        lib().okde_ers_set_flag_sink(None)
+        return False
+
+
 def ers_enhance(refined_depth, bgr, refined_labels, window=7, spatial_sigma=30.0, color_sigma=50.0,
                 depth_sigma=70.0):
     rd, bgr, rl = _f32(refined_depth), _u8(bgr), _i32(refined_labels)

@@ -95,8 +95,10 @@ def main():
     rl, rdepth = O.ers_edge_refining(g["k7_sp_labels"], g["k7_dasp_labels"], cd)
     g["k9_labels"], g["k9_depth"] = rl, rdepth
     g["k10_depth"] = O.ers_enhance(rdepth, cb, rl)
-    r = O.rgbf_process(cd, cp, cb, 3, 4, Kc)
+    with O.ers_flags((48, 64)) as rill:
+        r = O.rgbf_process(cd, cp, cb, 3, 4, Kc)
     g["rgbf_refined_depth"], g["rgbf_refined_labels"] = r["refined_depth"], r["refined_labels"]
+    g["rgbf_refined_depth_ill"] = rill.copy()
     np.savez_compressed(os.path.join(HERE, "golden_crops.npz"), **g)
     print("wrote golden_fullframe.json and golden_crops.npz:",
           {k: (v.shape, str(v.dtype)) for k, v in g.items()})

@@ -34,8 +34,9 @@ def test_main_replay_matches_oracle(torch_cuda, oracle, synth, color_fixture, tm
     jbf_ref, _, ill = oracle.jbf_process(depth, color_fixture, return_all=True)
     assert_depth_close(load("jbf"), jbf_ref, 1e-4, ill=ill, what="C++ JBF")
     assert_depth_close(load("mrf"), oracle.mrf_kernel(depth, color_fixture), 1e-4, what="C++ MRF")
-    rg = oracle.rgbf_process(depth, oracle.p2r_depth(depth, K), color_fixture, 15, 20, K)
-    assert_depth_close(load("rgbf"), rg["refined_depth"], 1e-4, what="C++ RGBF")
+    with oracle.ers_flags((480, 640)) as rill:
+        rg = oracle.rgbf_process(depth, oracle.p2r_depth(depth, K), color_fixture, 15, 20, K)
+    assert_depth_close(load("rgbf"), rg["refined_depth"], 1e-4, ill=rill, what="C++ RGBF")
     # the reference's only quality metric (main.cpp:220-308): mean 3-D error vs the averaged-depth cloud
     for name, d in (("input", depth), ("jbf", jbf_ref), ("rgbf", rg["refined_depth"])):
         e, n = oracle.mean_3d_error(oracle.p2r_depth(d, K), tpts)

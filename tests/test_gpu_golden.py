@@ -36,7 +36,7 @@ def test_golden_crops(torch_cuda, synth):
     assert np.array_equal(host(rg.getSPLabels_Device()), g["k7_sp_labels"])
     assert np.array_equal(host(rg.getDASPLabels_Device()), g["k7_dasp_labels"])
     assert np.array_equal(host(rg.getRefinedLabels_Device()), g["rgbf_refined_labels"])
-    assert_depth_close(host(rg.getRefinedDepth_Device()), g["rgbf_refined_depth"], 1e-4, what="golden RGBF")
+    assert_depth_close(host(rg.getRefinedDepth_Device()), g["rgbf_refined_depth"], 1e-4, ill=g["rgbf_refined_depth_ill"], what="golden RGBF")
     mrf = F.MarkovRandomField(64, 48)
     mrf.Process(dev(t, cd), dev(t, cb))
     assert_depth_close(host(mrf.getFiltered_Device()), g["mrf"], 1e-4, what="golden MRF")
