@@ -5,7 +5,9 @@
 // and the mean 3-D error of every method against the cloud of the averaged depth (main.cpp:220-308).
 //
 // usage: main_replay <width> <height> <color.bgr> <depth.f32> <averaged_depth.f32> <out_prefix>
-//   color.bgr: W*H*3 bytes packed BGR;  *.f32: W*H float32 millimetres
+//        main_replay <width> <height> <color.bgr> <depth.xml> - <out_prefix>      (the reference's own depth.xml)
+//   color.bgr: W*H*3 bytes packed BGR;  *.f32: W*H float32 millimetres;
+//   depth.xml: OpenCV FileStorage with "averaged_depth" and "depth" (main.cpp:112-114,146-149)
 // writes <out_prefix>{jbf,mrf,rgbf}.f32 and prints one "name error count" line per method.
 #include <hip/hip_runtime.h>
 
@@ -16,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include "../include/kde/depth_xml.hpp"
 #include "../include/kde/kde.hpp"
 
 #define HIP_OK(x)                                                                          \
@@ -72,8 +75,17 @@ int main(int argc, char** argv)
     const std::string prefix = argv[6];
     try {
         const std::vector<uint8_t> color = read_file<uint8_t>(argv[3], N * 3);
-        const std::vector<float> depth = read_file<float>(argv[4], N);
-        const std::vector<float> averaged = read_file<float>(argv[5], N);
+        std::vector<float> depth, averaged;
+        if (std::string(argv[5]) == "-") {
+            kde::DepthMatrix dm, am;
+            kde::read_depth_xml(argv[4], dm, am);
+            if (dm.rows != H || dm.cols != W || am.rows != H || am.cols != W) throw std::runtime_error("depth.xml size mismatch");
+            depth = dm.data;
+            averaged = am.data;
+        } else {
+            depth = read_file<float>(argv[4], N);
+            averaged = read_file<float>(argv[5], N);
+        }
 
         float *inputDepth_Device, *bufferDepth_Device;
         float3 *inputPoints_Device, *bufferPoints_Device, *tmpPoints_Device;

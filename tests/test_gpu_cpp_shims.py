@@ -42,5 +42,13 @@ def test_main_replay_matches_oracle(torch_cuda, oracle, synth, color_fixture, tm
         e, n = oracle.mean_3d_error(oracle.p2r_depth(d, K), tpts)
         assert lines[name][1] == n or abs(lines[name][1] - n) <= 3
         assert abs(lines[name][0] - e) <= 2e-3 * max(e, 1e-6), (name, lines[name], e)
+    # the same run fed through the reference's own file format (OpenCV FileStorage XML, main.cpp:146-149)
+    from kinectdepthmapenhancement_amd import xmlio
+    xmlio.write_depth_xml(str(tmp_path / "depth.xml"), depth, truth)
+    res2 = subprocess.run([exe, "640", "480", str(tmp_path / "color.bgr"), str(tmp_path / "depth.xml"), "-",
+                           str(tmp_path / "xml_")], capture_output=True, text=True, timeout=300)
+    assert res2.returncode == 0, res2.stderr
+    assert res2.stdout == res.stdout
+    assert np.array_equal(np.fromfile(str(tmp_path / "xml_jbf.f32"), np.float32), load("jbf").ravel())
     # (no "the filter reduces the error" check: with the reference's constants the Q1 rule gives far depth
     #  outliers full weight, so JBF smears depth edges and its mean 3-D error exceeds the input's)
