@@ -421,11 +421,17 @@ public:
         check(kde_spdsr_edge_enhanced_points_device(h_, &p));
         return reinterpret_cast<float3*>(p);
     }
-    float3* getOptimizedPoints_Device()   // throws KDE_ERR_UNSUPPORTED until the PCA/projection tail is built
+    float3* getOptimizedPoints_Device()
     {
         kde_float3* p = nullptr;
         check(kde_spdsr_optimized_points_device(h_, &p));
         return reinterpret_cast<float3*>(p);
+    }
+    float3* getOptimizedPoints_Host()
+    {
+        const kde_float3* p = nullptr;
+        check(kde_spdsr_optimized_points_host(h_, stream_, &p));
+        return reinterpret_cast<float3*>(const_cast<kde_float3*>(p));
     }
     void setStream(void* hip_stream) { stream_ = hip_stream; }
 

@@ -227,9 +227,9 @@ int kde_rgbf_dasp_labels_device(kde_rgbf* h, int32_t** out);
 
 /* ============================================================================================
  * SPDepthSuperResolution — SPDepthSuperResolution.{h,cpp}: class surface named by the north star.
- * Process runs the head (.cpp:57-64: SP(200,10,0,5), DASP(0,10,200,5), ERS, projectiveToReal).
- * The tail (host PCA + Projection_GPU::PlaneProjection, .cpp:65-190) is SURVEY §8 f2:
- * kde_spdsr_optimized_points_device returns KDE_ERR_UNSUPPORTED until it is built.
+ * Process = .cpp:57-191: SP(200,10,0,5), DASP(0,10,200,5), ERS, projectiveToReal, per-superpixel plane fit
+ * (the reference's host cv::PCA loop, here on the device) and Projection_GPU::PlaneProjection(nd, labels,
+ * points) (Projection_GPU/Projection_GPU.cu:55-81, 148-187, 274-294; 20 sweeps, snapshot semantics D5).
  * ========================================================================================== */
 typedef struct kde_spdsr kde_spdsr;
 int kde_spdsr_create(kde_spdsr** out, int width, int height);
@@ -241,7 +241,10 @@ int kde_spdsr_refined_depth_device(kde_spdsr* h, float** out);
 int kde_spdsr_refined_depth_host(kde_spdsr* h, void* stream, const float** out);
 int kde_spdsr_refined_labels_device(kde_spdsr* h, int32_t** out);
 int kde_spdsr_edge_enhanced_points_device(kde_spdsr* h, kde_float3** out);         /* EdgeEnhanced3DPoints_Device */
-int kde_spdsr_optimized_points_device(kde_spdsr* h, kde_float3** out);             /* getOptimizedPoints_Device   */
+int kde_spdsr_optimized_points_device(kde_spdsr* h, kde_float3** out);             /* getOptimizedPoints_Device (Projection_GPU.cpp:62-64) */
+int kde_spdsr_optimized_points_host(kde_spdsr* h, void* stream, const kde_float3** out); /* getOptimizedPoints_Host (:59-61) */
+int kde_spdsr_plane_fitted_points_device(kde_spdsr* h, kde_float3** out);         /* Projection_GPU::GetPlaneFitted3D_Device (:56-58) */
+int kde_spdsr_cluster_nd_device(kde_spdsr* h, float** out);                       /* ClusterND_Device: float4 {normal, distance} per cluster */
 
 /* ============================================================================================
  * Measurement helpers (bench.py): a float4 streaming copy for the empirical HBM ceiling

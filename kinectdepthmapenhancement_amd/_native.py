@@ -118,6 +118,9 @@ SIGNATURES = {
     "kde_spdsr_refined_labels_device": (_i, [_vp, _pp]),
     "kde_spdsr_edge_enhanced_points_device": (_i, [_vp, _pp]),
     "kde_spdsr_optimized_points_device": (_i, [_vp, _pp]),
+    "kde_spdsr_optimized_points_host": (_i, [_vp, _vp, _pp]),
+    "kde_spdsr_plane_fitted_points_device": (_i, [_vp, _pp]),
+    "kde_spdsr_cluster_nd_device": (_i, [_vp, _pp]),
     "kde_bench_copy": (_i, [_vp, _vp, _sz, _vp]),
 }
 

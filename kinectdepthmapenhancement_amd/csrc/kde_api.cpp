@@ -875,7 +875,15 @@ extern "C" int kde_rgbf_dasp_labels_device(kde_rgbf* h, int32_t** out)
 struct kde_spdsr {
     Pipeline p;
     kde_dimconv conv;
+    int nclusters = 0;
     DevBuf<kde_float3> edge_points;   // EdgeEnhanced3DPoints_Device
+    DevBuf<float> cluster_nd;         // ClusterND_Device (float4 per cluster)
+    DevBuf<double> sums, cov;         // per-cluster moments (replace the host cv::Mat / cv::PCA round trip)
+    DevBuf<float> nxy;                // Projection_GPU::Normalized3D_Device (x, y of the unit-depth ray)
+    DevBuf<kde_float3> plane_fitted;  // Projection_GPU::PlaneFitted3D_Device
+    DevBuf<kde_float3> opt_a, opt_b;  // Projection_GPU::Optimized3D_Device, double-buffered (D5)
+    kde_float3* optimized = nullptr;
+    PinnedBuf<kde_float3> optimized_host;
 };
 
 extern "C" int kde_spdsr_create(kde_spdsr** out, int width, int height)
@@ -885,7 +893,12 @@ extern "C" int kde_spdsr_create(kde_spdsr** out, int width, int height)
     kde_spdsr* h = new (std::nothrow) kde_spdsr;
     if (!h) return fail(KDE_ERR_NOMEM, "kde_spdsr_create: out of host memory");
     int rc = h->p.init(width, height);
-    if (rc == KDE_OK) rc = h->edge_points.alloc((size_t)width * height);   // SPDepthSuperResolution.cpp:19
+    const size_t px = (size_t)width * height;
+    if (rc == KDE_OK) rc = h->edge_points.alloc(px);   // SPDepthSuperResolution.cpp:19
+    if (rc == KDE_OK) rc = h->nxy.alloc(px * 2);        // Projection_GPU::initMemory (Projection_GPU.cpp:45-51)
+    if (rc == KDE_OK) rc = h->plane_fitted.alloc(px);
+    if (rc == KDE_OK) rc = h->opt_a.alloc(px);
+    if (rc == KDE_OK) rc = h->opt_b.alloc(px);
     if (rc != KDE_OK) { delete h; return rc; }
     *out = h;
     return KDE_OK;
@@ -898,15 +911,33 @@ extern "C" int kde_spdsr_set_parameters(kde_spdsr* h, int rows, int cols, const 
     KDE_REQUIRE(h, "kde_spdsr_set_parameters: null handle");
     KDE_TRY(kde_dasp_set_parameters(h->p.SP, rows, cols, K));       // SPDepthSuperResolution.cpp:46
     KDE_TRY(kde_dasp_set_parameters(h->p.DASP, rows, cols, K));     // :47
-    return kde_dimconv_set_camera(&h->conv, K, h->p.width, h->p.height);   // :48
+    KDE_TRY(kde_dimconv_set_camera(&h->conv, K, h->p.width, h->p.height));   // :48
+    // Projector = new Projection_GPU(Width, Height, intrinsic) (:49): same truncated intrinsics, initNormalized3D
+    h->nclusters = rows * cols;
+    KDE_TRY(h->cluster_nd.alloc((size_t)h->nclusters * 4));          // :52-53
+    KDE_TRY(h->sums.alloc((size_t)h->nclusters * 4));
+    KDE_TRY(h->cov.alloc((size_t)h->nclusters * 6));
+    KDE_HIP_TRY(hipMemset(h->cluster_nd.p, 0, (size_t)h->nclusters * 4 * sizeof(float)));
+    KDE_TRY(launch_spdsr_init_normalized(h->conv.cam, h->nxy.p, nullptr));
+    KDE_HIP_TRY(hipStreamSynchronize(nullptr));
+    return KDE_OK;
 }
 
 extern "C" int kde_spdsr_process(kde_spdsr* h, const float* depth_dev, const kde_float3* points_dev, const uint8_t* bgr_dev, void* stream)
 {
     KDE_REQUIRE(h && depth_dev && points_dev && bgr_dev, "kde_spdsr_process: null argument");
     // SPDepthSuperResolution.cpp:59-64
+    KDE_REQUIRE(h->nclusters > 0, "kde_spdsr_process: SetParametor was not called");
     KDE_TRY(h->p.run(depth_dev, points_dev, bgr_dev, 200.0f, 10.0f, 0.0f, 0.0f, 10.0f, 200.0f, 5, stream));
-    return kde_dimconv_projective_to_real_depth(&h->conv, 1, h->p.ERS->refined_depth.p, h->edge_points.p, stream);
+    KDE_TRY(kde_dimconv_projective_to_real_depth(&h->conv, 1, h->p.ERS->refined_depth.p, h->edge_points.p, stream));
+    // :65-170 on the device: per-cluster plane of the labelled cloud (no D2H / host PCA / H2D)
+    hipStream_t s = as_stream(stream);
+    KDE_TRY(launch_spdsr_cluster_planes(h->p.width, h->p.height, h->nclusters, h->p.ERS->labels_a.p, h->edge_points.p,
+                                        h->sums.p, h->cov.p, h->cluster_nd.p, s));
+    // Projector->PlaneProjection(ClusterND_Device, refined labels, EdgeEnhanced3DPoints_Device) (:190)
+    return launch_spdsr_plane_projection(h->p.width, h->p.height, h->nclusters, h->cluster_nd.p, h->p.ERS->labels_a.p,
+                                         h->edge_points.p, h->nxy.p, h->plane_fitted.p, h->opt_a.p, h->opt_b.p, 20,
+                                         &h->optimized, s);
 }
 
 extern "C" int kde_spdsr_refined_depth_device(kde_spdsr* h, float** out)
@@ -936,10 +967,36 @@ extern "C" int kde_spdsr_edge_enhanced_points_device(kde_spdsr* h, kde_float3** 
 
 extern "C" int kde_spdsr_optimized_points_device(kde_spdsr* h, kde_float3** out)
 {
-    (void)h;
-    if (out) *out = nullptr;
-    return fail(KDE_ERR_UNSUPPORTED,
-                "getOptimizedPoints: the PCA + plane-projection tail (SPDepthSuperResolution.cpp:65-190) is not built yet");
+    KDE_REQUIRE(h && out, "kde_spdsr_optimized_points_device: null argument");
+    KDE_REQUIRE(h->optimized, "getOptimizedPoints: Process has not run yet");
+    *out = h->optimized;
+    return KDE_OK;
+}
+
+extern "C" int kde_spdsr_optimized_points_host(kde_spdsr* h, void* stream, const kde_float3** out)
+{
+    KDE_REQUIRE(h && out, "kde_spdsr_optimized_points_host: null argument");
+    KDE_REQUIRE(h->optimized, "getOptimizedPoints: Process has not run yet");
+    const size_t px = (size_t)h->p.width * h->p.height;
+    KDE_TRY(h->optimized_host.ensure(px));
+    KDE_HIP_TRY(hipMemcpyAsync(h->optimized_host.p, h->optimized, px * sizeof(kde_float3), hipMemcpyDeviceToHost, as_stream(stream)));
+    KDE_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    *out = h->optimized_host.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_spdsr_plane_fitted_points_device(kde_spdsr* h, kde_float3** out)
+{
+    KDE_REQUIRE(h && out, "kde_spdsr_plane_fitted_points_device: null argument");
+    *out = h->plane_fitted.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_spdsr_cluster_nd_device(kde_spdsr* h, float** out)
+{
+    KDE_REQUIRE(h && out, "kde_spdsr_cluster_nd_device: null argument");
+    *out = h->cluster_nd.p;
+    return KDE_OK;
 }
 
 // =====================================================================================================

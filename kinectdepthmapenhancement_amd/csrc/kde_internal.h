@@ -184,4 +184,11 @@ int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bg
                        const float* s_eff, const float* table_host, int window, float color_sigma, float depth_sigma,
                        float exp_zero, float* out, hipStream_t s);
 
+int launch_spdsr_init_normalized(const Camera& c, float* nxy, hipStream_t s);
+int launch_spdsr_cluster_planes(int width, int height, int nclusters, const int32_t* labels, const kde_float3* pts,
+                                double* sums, double* cov, float* nd, hipStream_t s);
+int launch_spdsr_plane_projection(int width, int height, int nclusters, const float* nd, const int32_t* labels,
+                                  const kde_float3* pts, const float* nxy, kde_float3* plane_fitted, kde_float3* opt_a,
+                                  kde_float3* opt_b, int sweeps, kde_float3** result, hipStream_t s);
+
 }  // namespace kde

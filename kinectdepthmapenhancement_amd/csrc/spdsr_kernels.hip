@@ -1,0 +1,272 @@
+// spdsr_kernels.hip — the tail of SPDepthSuperResolution::Process on the device:
+//   * per-superpixel plane fit: the reference copies the cloud to the host, pushes every labelled point into
+//     a cv::Mat per cluster (W*H heap allocations per frame) and runs cv::PCA per cluster
+//     (SPDepthSuperResolution.cpp:65-142).  Here: two passes of double-precision moment accumulation
+//     (LDS atomics per workgroup, then one global atomic per touched cluster), and a 3x3 symmetric Jacobi
+//     eigen-solve per cluster — no host round trip;
+//   * Projection_GPU::PlaneProjection(nd, labels, points): setPsuedoDepth [sic] + copy
+//     (Projection_GPU.cu:55-81, 277-281) and 20 mrf_optimization sweeps (.cu:148-187, 282-285).  The sweeps
+//     are in place and racy in the reference; deviation D5: every sweep reads the previous sweep's result.
+// The accumulation order of the double sums is not fixed (atomics); results agree with the serial restatement
+// to ~1e-15 relative before the cast to float.
+#include "kde_internal.h"
+
+namespace kde {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxLdsClusters = 1024;   // 4 or 6 doubles per cluster in LDS
+
+// ---- moments ---------------------------------------------------------------------------------------------
+template <bool COV>
+__global__ __launch_bounds__(kThreads) void cluster_moments_kernel(int npix, int nclusters, int use_lds,
+                                                                   const int32_t* __restrict__ labels,
+                                                                   const kde_float3* __restrict__ pts,
+                                                                   double* __restrict__ sums,   // [k][4]: n, sx, sy, sz
+                                                                   double* __restrict__ cov)    // [k][6]
+{
+    constexpr int NV = COV ? 6 : 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* acc = reinterpret_cast<double*>(smem);
+    if (use_lds) {
+        for (int i = threadIdx.x; i < nclusters * NV; i += kThreads) acc[i] = 0.0;
+        __syncthreads();
+    }
+    double* out = COV ? cov : sums;
+    const int per_block = kThreads * 16;
+    const int begin = blockIdx.x * per_block;
+    const int end = begin + per_block < npix ? begin + per_block : npix;
+    for (int i = begin + threadIdx.x; i < end; i += kThreads) {
+        const int l = labels[i];
+        if (l < 0 || l >= nclusters) continue;       // label != -1 (SPDepthSuperResolution.cpp:70)
+        const kde_float3 p = pts[i];
+        double v[NV];
+        if (!COV) {
+            v[0] = 1.0; v[1] = (double)p.x; v[2] = (double)p.y; v[3] = (double)p.z;
+        } else {
+            const double n = sums[l * 4];
+            const double dx = (double)p.x - sums[l * 4 + 1] / n, dy = (double)p.y - sums[l * 4 + 2] / n,
+                         dz = (double)p.z - sums[l * 4 + 3] / n;
+            v[0] = dx * dx; v[1] = dx * dy; v[2] = dx * dz; v[3] = dy * dy; v[4] = dy * dz; v[5] = dz * dz;
+        }
+        double* dst = use_lds ? acc + l * NV : out + l * NV;
+#pragma unroll
+        for (int k = 0; k < NV; k++) atomicAdd(dst + k, v[k]);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nclusters * NV; i += kThreads)
+            if (acc[i] != 0.0) atomicAdd(out + i, acc[i]);
+    }
+}
+
+// ---- plane per cluster (cv::PCA + sign convention, SPDepthSuperResolution.cpp:84-138) -----------------------
+__device__ void jacobi_eigen3(double A[3][3], double evals[3], double evecs[3][3])
+{
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; sweep++) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (off == 0.0) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; k++) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 2; i++)
+        for (int j = i + 1; j < 3; j++)
+            if (A[order[j]][order[j]] > A[order[i]][order[i]]) {
+                const int t = order[i];
+                order[i] = order[j];
+                order[j] = t;
+            }
+    for (int i = 0; i < 3; i++) {
+        evals[i] = A[order[i]][order[i]];
+        for (int k = 0; k < 3; k++) evecs[i][k] = V[k][order[i]];
+    }
+}
+
+__global__ __launch_bounds__(64) void cluster_planes_kernel(int nclusters, const double* __restrict__ sums,
+                                                           const double* __restrict__ cov, float4* __restrict__ nd)
+{
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= nclusters) return;
+    const double cnt = sums[l * 4];
+    if (cnt >= 3.0) {
+        double A[3][3] = {{cov[l * 6] / cnt, cov[l * 6 + 1] / cnt, cov[l * 6 + 2] / cnt},
+                          {cov[l * 6 + 1] / cnt, cov[l * 6 + 3] / cnt, cov[l * 6 + 4] / cnt},
+                          {cov[l * 6 + 2] / cnt, cov[l * 6 + 4] / cnt, cov[l * 6 + 5] / cnt}};
+        double ev[3], evec[3][3];
+        jacobi_eigen3(A, ev, evec);
+        float nx = (float)evec[2][0], ny = (float)evec[2][1], nz = (float)evec[2][2];
+        const double gx = sums[l * 4 + 1] / cnt, gy = sums[l * 4 + 2] / cnt, gz = sums[l * 4 + 3] / cnt;
+        const double plane_d_tmp = nx * gx + ny * gy + nz * gz;
+        if (plane_d_tmp < 0) {
+            nx = (float)(nx * -1.0);
+            ny = (float)(ny * -1.0);
+            nz = (float)(nz * -1.0);
+        }
+        nd[l] = make_float4(nx, ny, nz, (float)fabs(plane_d_tmp));
+    } else {
+        float4 v = nd[l];                 // w keeps its previous value, like the reference's pinned ClusterND_Host
+        v.x = v.y = v.z = 5.0f;
+        nd[l] = v;
+    }
+}
+
+// ---- Projection_GPU ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void init_normalized_kernel(Camera c, float2* __restrict__ nxy)
+{
+    // initTemp, Projection_GPU.cu:3-19 (D4: every pixel is covered)
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= c.width || y >= c.height) return;
+    float tx = (float)x, ty = (float)y;
+    ty = (float)c.cy - ty;
+    tx = tx - (float)c.cx;
+    tx /= c.fx;
+    ty /= c.fy;
+    nxy[(size_t)y * c.width + x] = make_float2(tx * 1.0f, ty * 1.0f);
+}
+
+__global__ __launch_bounds__(kThreads) void set_pseudo_depth_kernel(int npix, int nclusters, const float4* __restrict__ nd,
+                                                                   const int32_t* __restrict__ labels,
+                                                                   const kde_float3* __restrict__ pts,
+                                                                   const float2* __restrict__ nxy,
+                                                                   kde_float3* __restrict__ plane_fitted,
+                                                                   kde_float3* __restrict__ optimized)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= npix) return;
+    const int l = labels[i];
+    const kde_float3 p = pts[i];
+    kde_float3 pf = p;
+    if (l > -1 && l < nclusters) {
+        const float4 n = nd[l];
+        if (fabsf(n.x) < 1.0f) {                     // Projection_GPU.cu:70 (normal (5,5,5) marks "no plane")
+            const float2 r = nxy[i];
+            const float z = fabsf(n.w / (n.x * r.x + n.y * r.y + n.z));
+            pf.z = z;
+            pf.x = z * r.x;
+            pf.y = z * r.y;
+        }
+    }
+    plane_fitted[i] = pf;
+    optimized[i] = p;                                 // the cudaMemcpy of .cu:281
+}
+
+constexpr int kSwTX = 64, kSwTY = 4;
+__global__ __launch_bounds__(kThreads) void mrf_sweep_kernel(int width, int height, const kde_float3* __restrict__ in,
+                                                            const kde_float3* __restrict__ plane_fitted,
+                                                            const float2* __restrict__ nxy, kde_float3* __restrict__ out)
+{
+    // mrf_optimization, Projection_GPU.cu:148-187 with (window 5, K 0.5, smooth_sigma 1.0)
+    constexpr int R = 2, LW = kSwTX + 2 * R, LH = kSwTY + 2 * R;
+    __shared__ float sz[LH * LW];
+    const int x0 = blockIdx.x * kSwTX, y0 = blockIdx.y * kSwTY;
+    for (int i = threadIdx.x; i < LW * LH; i += kThreads) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gx = x0 + lx - R, gy = y0 + ly - R;
+        float z = 0.0f;
+        if (gx >= 0 && gx < width && gy >= 0 && gy < height) z = in[(size_t)gy * width + gx].z;
+        sz[i] = z > 50.0f ? z : 0.0f;                 // taps need optimized.z > 50 (.cu:167)
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= width || y >= height) return;
+    const size_t p = (size_t)y * width + x;
+    kde_float3 o = in[p];
+    const float pf = plane_fitted[p].z;
+    if (pf > 50.0f && fabsf(o.z - pf) < o.z * 0.01f) {
+        float numerator = pf, denominator = 1.0f;
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const float oq = sz[(ty + i) * LW + tx + j];
+                const float diff = fabsf(o.z - oq);
+                // K / (1 + diff^2) * smooth_sigma with K = 0.5, smooth_sigma = 1; v_rcp_f32 (1 ulp) for the division
+                float filter = 0.5f * __builtin_amdgcn_rcpf(1.0f + diff * diff);
+                filter = oq > 0.0f ? filter : 0.0f;
+                numerator = __builtin_fmaf(oq, filter, numerator);
+                denominator += filter;
+            }
+        if (denominator != 0.0f) {
+            const float depth = numerator / denominator;
+            const float2 r = nxy[p];
+            o.z = depth;
+            o.x = r.x * depth;
+            o.y = r.y * depth;
+        }
+    }
+    out[p] = o;
+}
+
+}  // namespace
+
+int launch_spdsr_init_normalized(const Camera& c, float* nxy, hipStream_t s)
+{
+    hipLaunchKernelGGL(init_normalized_kernel, dim3(ceil_div(c.width, 64), ceil_div(c.height, 4)), dim3(kThreads), 0, s, c,
+                       reinterpret_cast<float2*>(nxy));
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_spdsr_cluster_planes(int width, int height, int nclusters, const int32_t* labels, const kde_float3* pts,
+                                double* sums, double* cov, float* nd, hipStream_t s)
+{
+    const int npix = width * height;
+    KDE_HIP_TRY(hipMemsetAsync(sums, 0, (size_t)nclusters * 4 * sizeof(double), s));
+    KDE_HIP_TRY(hipMemsetAsync(cov, 0, (size_t)nclusters * 6 * sizeof(double), s));
+    const int use_lds = nclusters <= kMaxLdsClusters;
+    const int blocks = ceil_div(npix, kThreads * 16);
+    hipLaunchKernelGGL(cluster_moments_kernel<false>, dim3(blocks), dim3(kThreads), use_lds ? (size_t)nclusters * 4 * 8 : 0, s,
+                       npix, nclusters, use_lds, labels, pts, sums, cov);
+    hipLaunchKernelGGL(cluster_moments_kernel<true>, dim3(blocks), dim3(kThreads), use_lds ? (size_t)nclusters * 6 * 8 : 0, s,
+                       npix, nclusters, use_lds, labels, pts, sums, cov);
+    hipLaunchKernelGGL(cluster_planes_kernel, dim3(ceil_div(nclusters, 64)), dim3(64), 0, s, nclusters, sums, cov,
+                       reinterpret_cast<float4*>(nd));
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+int launch_spdsr_plane_projection(int width, int height, int nclusters, const float* nd, const int32_t* labels,
+                                  const kde_float3* pts, const float* nxy, kde_float3* plane_fitted, kde_float3* opt_a,
+                                  kde_float3* opt_b, int sweeps, kde_float3** result, hipStream_t s)
+{
+    const int npix = width * height;
+    hipLaunchKernelGGL(set_pseudo_depth_kernel, dim3(ceil_div(npix, kThreads)), dim3(kThreads), 0, s, npix, nclusters,
+                       reinterpret_cast<const float4*>(nd), labels, pts, reinterpret_cast<const float2*>(nxy), plane_fitted, opt_a);
+    kde_float3 *in = opt_a, *out = opt_b;
+    dim3 grid(ceil_div(width, kSwTX), ceil_div(height, kSwTY));
+    for (int i = 0; i < sweeps; i++) {
+        hipLaunchKernelGGL(mrf_sweep_kernel, grid, dim3(kThreads), 0, s, width, height, in, plane_fitted,
+                           reinterpret_cast<const float2*>(nxy), out);
+        kde_float3* t = in;
+        in = out;
+        out = t;
+    }
+    KDE_HIP_TRY(hipGetLastError());
+    *result = in;
+    return KDE_OK;
+}
+
+}  // namespace kde

@@ -410,7 +410,7 @@ class RegionGrowingBilateralFilter(_PipelineBase):
 
 
 class SPDepthSuperResolution(_PipelineBase):
-    """SPDepthSuperResolution.h:17-46 (head built; getOptimizedPoints_* raise until the f2 tail exists)."""
+    """SPDepthSuperResolution.h:17-46."""
     _destroy = "kde_spdsr_destroy"
     _prefix = "kde_spdsr"
 
@@ -419,6 +419,17 @@ class SPDepthSuperResolution(_PipelineBase):
 
     def getOptimizedPoints_Device(self):
         return self._get("optimized_points_device", (self.Height, self.Width, 3), torch.float32)
+
+    def getOptimizedPoints_Host(self) -> np.ndarray:
+        p = C.c_void_p()
+        check(lib().kde_spdsr_optimized_points_host(self._h, _stream(), C.byref(p)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(self.Height, self.Width, 3)).copy()
+
+    def getPlaneFitted3D_Device(self):
+        return self._get("plane_fitted_points_device", (self.Height, self.Width, 3), torch.float32)
+
+    def getClusterND_Device(self):
+        return self._get("cluster_nd_device", (self.sp_rows * self.sp_cols, 4), torch.float32)
 
 
 def hbm_copy(src: torch.Tensor, dst: torch.Tensor) -> None:

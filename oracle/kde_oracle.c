@@ -982,3 +982,171 @@ double okde_mean_3d_error(int n, const okde_float3* pts, const okde_float3* trut
     if (count_out) *count_out = count;
     return (double)(acc / (float)count);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * SPDepthSuperResolution::Process tail (next-row f2) — SPDepthSuperResolution.cpp:65-170 and
+ * Projection_GPU::PlaneProjection(nd, labels, points) — Projection_GPU/Projection_GPU.cu:3-19, 55-81,
+ * 148-187, 274-294; constants Projection_GPU.cpp:3-5 (unused by this overload) and the literal
+ * (window 5, K 0.5, smooth 1.0, 20 sweeps) of .cu:282-285.
+ *
+ * Host part: every pixel whose refined label is not -1 contributes its back-projected point (valid or
+ * not) to its cluster; clusters with >= 3 points get cv::PCA (mean, covariance/n, symmetric eigen
+ * decomposition; third eigenvector = normal, flipped so that normal.mean >= 0; d = |normal.mean|),
+ * the others get normal (5,5,5).  cv::PCA is third-party (OpenCV 2.4.3 core); its eigen() is restated as
+ * a cyclic Jacobi iteration in double, eigenvalues in descending order.
+ * Device part: setPsuedoDepth (sic), copy, 20 mrf_optimization sweeps.  The sweeps are in place and racy
+ * in the reference; deviation D5: each sweep reads the previous sweep's result (Jacobi / snapshot).
+ * ---------------------------------------------------------------------------------------- */
+static void jacobi_eigen3(double A[3][3], double evals[3], double evecs[3][3])
+{
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (off == 0.0) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (A[p][q] == 0.0) continue;
+                double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; k++) {           /* A <- A J */
+                    double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; k++) {           /* A <- J^T A */
+                    double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; k++) {           /* V <- V J */
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 2; i++)
+        for (int j = i + 1; j < 3; j++)
+            if (A[order[j]][order[j]] > A[order[i]][order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+    for (int i = 0; i < 3; i++) {
+        evals[i] = A[order[i]][order[i]];
+        for (int k = 0; k < 3; k++) evecs[i][k] = V[k][order[i]];   /* eigenvectors as rows */
+    }
+}
+
+void okde_spdsr_cluster_planes(int width, int height, int nclusters, const int32_t* labels,
+                               const okde_float3* points, float* nd /* nclusters*4, in/out */)
+{
+    const size_t n = (size_t)width * height;
+    double* sum = (double*)calloc((size_t)nclusters * 4, sizeof(double));   /* count, x, y, z */
+    double* cov = (double*)calloc((size_t)nclusters * 6, sizeof(double));   /* xx xy xz yy yz zz */
+    for (size_t i = 0; i < n; i++) {
+        int l = labels[i];
+        if (l < 0 || l >= nclusters) continue;      /* label != -1 (.cpp:70); labels beyond the table are ignored */
+        sum[l * 4] += 1.0;
+        sum[l * 4 + 1] += (double)points[i].x;
+        sum[l * 4 + 2] += (double)points[i].y;
+        sum[l * 4 + 3] += (double)points[i].z;
+    }
+    for (int l = 0; l < nclusters; l++)
+        if (sum[l * 4] > 0) { sum[l * 4 + 1] /= sum[l * 4]; sum[l * 4 + 2] /= sum[l * 4]; sum[l * 4 + 3] /= sum[l * 4]; }
+    for (size_t i = 0; i < n; i++) {
+        int l = labels[i];
+        if (l < 0 || l >= nclusters) continue;
+        double dx = (double)points[i].x - sum[l * 4 + 1], dy = (double)points[i].y - sum[l * 4 + 2],
+               dz = (double)points[i].z - sum[l * 4 + 3];
+        cov[l * 6] += dx * dx; cov[l * 6 + 1] += dx * dy; cov[l * 6 + 2] += dx * dz;
+        cov[l * 6 + 3] += dy * dy; cov[l * 6 + 4] += dy * dz; cov[l * 6 + 5] += dz * dz;
+    }
+    for (int l = 0; l < nclusters; l++) {
+        const double cnt = sum[l * 4];
+        if (cnt >= 3.0) {                            /* .cpp:84 */
+            double A[3][3] = {{cov[l * 6] / cnt, cov[l * 6 + 1] / cnt, cov[l * 6 + 2] / cnt},
+                              {cov[l * 6 + 1] / cnt, cov[l * 6 + 3] / cnt, cov[l * 6 + 4] / cnt},
+                              {cov[l * 6 + 2] / cnt, cov[l * 6 + 4] / cnt, cov[l * 6 + 5] / cnt}};
+            double ev[3], evec[3][3];
+            jacobi_eigen3(A, ev, evec);
+            float nx = (float)evec[2][0], ny = (float)evec[2][1], nz = (float)evec[2][2];   /* .cpp:88-91 */
+            const double gx = sum[l * 4 + 1], gy = sum[l * 4 + 2], gz = sum[l * 4 + 3];
+            double plane_d_tmp = nx * gx + ny * gy + nz * gz;                               /* .cpp:105 */
+            if (plane_d_tmp < 0) { nx = (float)(nx * -1.0); ny = (float)(ny * -1.0); nz = (float)(nz * -1.0); }
+            nd[l * 4] = nx; nd[l * 4 + 1] = ny; nd[l * 4 + 2] = nz;
+            nd[l * 4 + 3] = (float)fabs(plane_d_tmp);                                       /* .cpp:119-121 */
+        } else {
+            nd[l * 4] = 5.0f; nd[l * 4 + 1] = 5.0f; nd[l * 4 + 2] = 5.0f;                    /* .cpp:134-138; w untouched */
+        }
+    }
+    free(sum);
+    free(cov);
+}
+
+void okde_projection_plane(int width, int height, float fx, float fy, int cx, int cy, const float* nd,
+                           int nclusters, const int32_t* labels, const okde_float3* points,
+                           okde_float3* plane_fitted, okde_float3* optimized, int sweeps)
+{
+    const size_t n = (size_t)width * height;
+    float* nxy = (float*)malloc(n * 2 * sizeof(float));     /* Normalized3D (initTemp, .cu:3-19) */
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            float tx = (float)x, ty = (float)y;
+            ty = (float)cy - ty;
+            tx = tx - (float)cx;
+            tx /= fx;
+            ty /= fy;
+            tx *= 1.0f;
+            ty *= 1.0f;
+            nxy[2 * ((size_t)y * width + x)] = tx;
+            nxy[2 * ((size_t)y * width + x) + 1] = ty;
+        }
+    /* setPsuedoDepth, .cu:55-81 */
+    for (size_t i = 0; i < n; i++) {
+        int l = labels[i];
+        if (l > -1 && l < nclusters && fabsf(nd[l * 4]) < 1.0f) {
+            float a = nd[l * 4], b = nd[l * 4 + 1], c = nd[l * 4 + 2], d = nd[l * 4 + 3];
+            float z = fabsf(d / (a * nxy[2 * i] + b * nxy[2 * i + 1] + c));
+            plane_fitted[i].z = z;
+            plane_fitted[i].x = z * nxy[2 * i];
+            plane_fitted[i].y = z * nxy[2 * i + 1];
+        } else {
+            plane_fitted[i] = points[i];
+        }
+    }
+    memcpy(optimized, points, n * sizeof(okde_float3));     /* .cu:281 */
+    okde_float3* prev = (okde_float3*)malloc(n * sizeof(okde_float3));
+    const int hw = 5 / 2;
+    const float Kc = 0.5f, smooth = 1.0f;
+    for (int it = 0; it < sweeps; it++) {                   /* .cu:282-285; D5: snapshot per sweep */
+        memcpy(prev, optimized, n * sizeof(okde_float3));
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+        for (int y = 0; y < height; y++)
+            for (int x = 0; x < width; x++) {
+                const size_t p = (size_t)y * width + x;
+                const float pf = plane_fitted[p].z, o = prev[p].z;
+                if (pf > 50.0f && fabsf(o - pf) < o * 0.01f) {
+                    float numerator = pf, denominator = 1.0f;
+                    for (int i = -hw; i <= hw; i++)
+                        for (int j = -hw; j <= hw; j++) {
+                            int xj = x + j, yi = y + i;
+                            if (xj >= 0 && xj < width && yi >= 0 && yi < height && prev[(size_t)yi * width + xj].z > 50.0f) {
+                                float oq = prev[(size_t)yi * width + xj].z;
+                                float diff = fabsf(o - oq);
+                                float depth_filter = Kc / (1 + diff * diff);
+                                float filter = smooth * depth_filter;
+                                numerator += oq * filter;
+                                denominator += filter;
+                            }
+                        }
+                    if (denominator != 0.0f) {
+                        float depth = numerator / denominator;
+                        optimized[p].z = depth;
+                        optimized[p].x = nxy[2 * p] * depth;
+                        optimized[p].y = nxy[2 * p + 1] * depth;
+                    }
+                }
+            }
+    }
+    free(prev);
+    free(nxy);
+}

@@ -131,6 +131,14 @@ int okde_spdsr_head(int width, int height, int rows, int cols, const double* K9,
                     const float* depth, const okde_float3* points, const uint8_t* bgr,
                     int32_t* refined_labels, float* refined_depth, okde_float3* refined_points);
 
+/* SPDepthSuperResolution::Process tail (f2): per-cluster plane (host PCA, SPDepthSuperResolution.cpp:65-170)
+ * and Projection_GPU::PlaneProjection(nd, labels, points) (Projection_GPU.cu:55-81, 148-187, 274-294) */
+void okde_spdsr_cluster_planes(int width, int height, int nclusters, const int32_t* labels,
+                               const okde_float3* points, float* nd);
+void okde_projection_plane(int width, int height, float fx, float fy, int cx, int cy, const float* nd,
+                           int nclusters, const int32_t* labels, const okde_float3* points,
+                           okde_float3* plane_fitted, okde_float3* optimized, int sweeps);
+
 /* main.cpp:220-308 — mean Euclidean 3-D error (mm) over pixels valid (50<z<15000) in both */
 double okde_mean_3d_error(int n, const okde_float3* pts, const okde_float3* truth, int* count_out);
 

@@ -327,6 +327,28 @@ def spdsr_head(depth, points, bgr, rows, cols, K):
     return rl, rd, rp
 
 
+def spdsr_cluster_planes(labels, points, nclusters, nd_prev=None):
+    """ClusterND (float4 per cluster: normal.xyz, plane distance) as SPDepthSuperResolution.cpp:65-170 computes it"""
+    lab, pts = _i32(labels), _pts(points)
+    h, w = lab.shape
+    nd = np.zeros((nclusters, 4), np.float32) if nd_prev is None else np.ascontiguousarray(nd_prev, np.float32).copy()
+    lib().okde_spdsr_cluster_planes(w, h, nclusters, _p(lab), _p(pts), _p(nd))
+    return nd
+
+
+def projection_plane(nd, labels, points, K, sweeps=20):
+    """Projection_GPU::PlaneProjection(nd, labels, points): (plane_fitted, optimized) float3 images"""
+    lab, pts = _i32(labels), _pts(points)
+    h, w = lab.shape
+    nd = np.ascontiguousarray(nd, np.float32)
+    fx, fy, cx, cy = camera_from_K(K)
+    pf = np.empty((h, w), FLOAT3)
+    opt = np.empty((h, w), FLOAT3)
+    lib().okde_projection_plane(w, h, C.c_float(fx), C.c_float(fy), cx, cy, _p(nd), nd.shape[0], _p(lab), _p(pts),
+                                _p(pf), _p(opt), sweeps)
+    return pf, opt
+
+
 def mean_3d_error(points, truth):
     a, b = _pts(points), _pts(truth)
     cnt = C.c_int(0)

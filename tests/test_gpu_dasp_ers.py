@@ -182,8 +182,9 @@ def test_full_chain_config5_1080p_properties(torch_cuda, F, synth):
     assert t.equal(t.nan_to_num(rg.getRefinedDepth_Device()), t.nan_to_num(again))      # deterministic (race-free)
 
 
-def test_spdsr_head_and_unbuilt_tail(torch_cuda, F, oracle, synth, frame):
-    from kinectdepthmapenhancement_amd import KdeError
+def test_spdsr_process_head_and_tail(torch_cuda, F, oracle, synth, frame):
+    """SPDepthSuperResolution::Process end to end: head (DASPx2 with 5 iterations, ERS, back-projection) and tail
+    (per-superpixel PCA plane + Projection_GPU::PlaneProjection with 20 sweeps, SPDepthSuperResolution.cpp:65-190)."""
     w, h = 320, 240
     bgr, depth, K, pts = _inputs(oracle, synth, frame, 14, w, h)
     sp = F.SPDepthSuperResolution(w, h)
@@ -194,6 +195,47 @@ def test_spdsr_head_and_unbuilt_tail(torch_cuda, F, oracle, synth, frame):
     assert np.array_equal(host(sp.getRefinedLabels_Device()), rl)
     got = host(sp.getRefinedDepth_Device())
     assert_depth_close(got, rd, 1e-4, ill=ill, what="SPDSR head depth")
-    assert np.array_equal(host(sp.getEdgeEnhanced3DPoints_Device()), pts_as_f32(oracle.p2r_depth(got, K)), equal_nan=True)
-    with pytest.raises(KdeError):
-        sp.getOptimizedPoints_Device()
+    gpts = host(sp.getEdgeEnhanced3DPoints_Device())
+    assert np.array_equal(gpts, pts_as_f32(oracle.p2r_depth(got, K)), equal_nan=True)
+    # tail, evaluated by the oracle on the GPU's own head output (plane fits are continuous in it)
+    gp = np.ascontiguousarray(gpts).view(oracle.FLOAT3).reshape(h, w)
+    nd_ref = oracle.spdsr_cluster_planes(rl, gp, 48)
+    nd = host(sp.getClusterND_Device())
+    assert np.all(np.abs(nd_ref[:, 0]) < 1.0)                    # every cluster of this frame has a plane
+    assert np.allclose(nd, nd_ref, rtol=2e-5, atol=2e-6), np.abs(nd - nd_ref).max()
+    assert np.allclose(np.linalg.norm(nd[:, :3], axis=1), 1.0, atol=1e-5)
+    pf_ref, opt_ref = oracle.projection_plane(nd, rl, gp, K, 20)        # same planes -> isolates the projection kernels
+    pf = host(sp.getPlaneFitted3D_Device())
+    fin = np.isfinite(pts_as_f32(pf_ref)).all(-1) & np.isfinite(pf).all(-1)
+    assert np.allclose(pf[fin], pts_as_f32(pf_ref)[fin], rtol=1e-5, atol=1e-3)
+    opt = host(sp.getOptimizedPoints_Device())
+    ro = pts_as_f32(opt_ref)
+    fin = np.isfinite(ro).all(-1) & np.isfinite(opt).all(-1)
+    assert fin.mean() > 0.99
+    assert_depth_close(opt[..., 2][fin], ro[..., 2][fin], 1e-4, what="optimized z")
+    assert np.allclose(opt[fin], ro[fin], rtol=2e-4, atol=2e-2)
+    assert (ro[..., 2] != gpts[..., 2]).mean() > 0.05                  # the sweeps actually moved points
+    assert np.array_equal(sp.getOptimizedPoints_Host(), opt, equal_nan=True)
+
+
+def test_spdsr_tail_degenerate_clusters(torch_cuda, F, oracle, synth):
+    """clusters with fewer than 3 labelled points get the (5,5,5) marker and leave their pixels untouched"""
+    w, h = 64, 48
+    K = synth.intrinsics(w, h)
+    depth = np.zeros((h, w), np.float32)            # every pixel invalid -> DASP labels -1 (depth sigma != 0)
+    depth[10:30, 10:50] = 1500.0
+    bgr = np.full((h, w, 3), 60, np.uint8)
+    pts = oracle.p2r_depth(depth, K)
+    sp = F.SPDepthSuperResolution(w, h)
+    sp.SetParametor(3, 4, K)
+    sp.Process(dev(torch_cuda, depth), dev(torch_cuda, pts_as_f32(pts)), dev(torch_cuda, bgr))
+    rl = host(sp.getRefinedLabels_Device())
+    gpts = host(sp.getEdgeEnhanced3DPoints_Device())
+    gp = np.ascontiguousarray(gpts).view(oracle.FLOAT3).reshape(h, w)
+    nd_ref = oracle.spdsr_cluster_planes(rl, gp, 12)
+    nd = host(sp.getClusterND_Device())
+    assert (nd_ref[:, 0] == 5.0).any()
+    marker = nd_ref[:, 0] == 5.0
+    assert np.array_equal(nd[marker, :3], nd_ref[marker, :3])
+    # (the flat patch makes K10 emit NaNs (Q6); they propagate into the moments of their cluster on both sides)
+    assert np.allclose(nd[~marker], nd_ref[~marker], rtol=2e-5, atol=2e-6, equal_nan=True)
