@@ -268,6 +268,44 @@ def side_measurements(torch, filters, synth, args):
     e1.record()
     torch.cuda.synchronize()
     out["float4_copy_GBs"] = 2 * 4 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+
+    # BASELINE config 5: full chain on one 1080p frame (projectiveToReal -> JBF.Process -> projectiveToReal ->
+    # RGBF.Process fed with the JBF output), and the HBM-bound feeder projectiveToReal on a 32-frame batch
+    W, H = 1920, 1080
+    bgr, depth = synth.make_frame(2000, W, H)
+    K = synth.intrinsics(W, H)
+    color, d = torch.from_numpy(bgr).cuda(), torch.from_numpy(depth).cuda()
+    conv = filters.DimensionConvertor()
+    conv.setCameraParameters(K, W, H)
+    jbf = filters.JointBilateralFilter(W, H)
+    rg = filters.RegionGrowingBilateralFilter(W, H)
+    rg.SetParametor(15, 20, K)
+    pts = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    filt = jbf.getFiltered_Device()
+
+    def chain():
+        conv.projectiveToReal(d, pts)
+        jbf.Process(d, color)
+        conv.projectiveToReal(filt, pts)
+        rg.Process(filt, pts, color)
+
+    def timed(fn, iters=10):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    ms = timed(chain)
+    out["fhd_full_chain_config5"] = {"ms_per_frame": ms, "mpix_s": W * H / ms / 1e3, "rows": 15, "cols": 20}
+    db = d[None].repeat(32, 1, 1).contiguous()
+    pb = torch.empty((32, H, W, 3), dtype=torch.float32, device="cuda")
+    ms = timed(lambda: conv.projectiveToReal(db, pb))
+    out["projectiveToReal_32xfhd"] = {"ms": ms, "GBs": 16.0 * 32 * W * H / ms / 1e6, "hbm_frac": 16.0 * 32 * W * H / ms / 1e6 / HBM_PEAK_GBS}
     return out
 
 

@@ -102,91 +102,108 @@ struct ClusterRec {   // LDS copy of one cluster: 32 B
 
 constexpr int kMaxLdsClusters = 2048;   // 64 KiB of LDS
 
-template <bool USE_LDS>
+// One segmenter's view of the assignment step.  RGBF / SPDSR run TWO segmenters (colour-only SP and
+// depth-adaptive DASP) on the same colour + cloud: NS = 2 assigns both label maps in one pass over the pixels
+// (colour and depth are read once, one launch instead of two); results are identical to two separate launches.
+struct CalcSet {
+    kde_label_distance* ld;
+    const kde_superpixel* mean;
+    const kde_float3* centers;
+    int32_t* labels;
+    float kc, ks, kd;
+    int depth_on;
+};
+template <int NS>
+struct CalcSets {
+    CalcSet s[NS];
+};
+
+template <int NS, bool USE_LDS>
 __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
-                                                     const kde_float3* __restrict__ pts,
-                                                     kde_label_distance* __restrict__ ld,
-                                                     const kde_superpixel* __restrict__ mean,
-                                                     const kde_float3* __restrict__ centers,
-                                                     int32_t* __restrict__ labels, float kc, float ks, float kd,
-                                                     float win2, int depth_on)
+                                                     const kde_float3* __restrict__ pts, CalcSets<NS> sets, float win2)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ClusterRec* recs = reinterpret_cast<ClusterRec*>(smem);
     const int nclusters = g.rows * g.cols;
     if (USE_LDS) {
-        for (int i = threadIdx.x; i < nclusters; i += 256) {
-            const kde_superpixel m = mean[i];
-            ClusterRec r;
-            r.r = (float)m.r;
-            r.g = (float)m.g;
-            r.b = (float)m.b;
-            r.x = m.x;
-            r.y = m.y;
-            r.cz = centers[i].z;
-            r.pad0 = r.pad1 = 0;
-            recs[i] = r;
-        }
+#pragma unroll
+        for (int n = 0; n < NS; n++)
+            for (int i = threadIdx.x; i < nclusters; i += 256) {
+                const kde_superpixel m = sets.s[n].mean[i];
+                ClusterRec r;
+                r.r = (float)m.r;
+                r.g = (float)m.g;
+                r.b = (float)m.b;
+                r.x = m.x;
+                r.y = m.y;
+                r.cz = sets.s[n].centers[i].z;
+                r.pad0 = r.pad1 = 0;
+                recs[n * nclusters + i] = r;
+            }
         __syncthreads();
     }
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= g.width || y >= g.height) return;
     const size_t p = (size_t)y * g.width + x;
-    const kde_label_distance cur = ld[p];
-    const int ccx = cur.l % g.cols, ccy = cur.l / g.cols;
     const float c0 = (float)bgr[p * 3], c1 = (float)bgr[p * 3 + 1], c2 = (float)bgr[p * 3 + 2];
     const float z = pts[p].z;
 
-    float dist[16];
-    int lab[16];
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
-        const int rx = ccx - 2 + (t & 3), ry = ccy - 2 + (t >> 2);
-        if (rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows) {
-            const int id = ry * g.cols + rx;
-            float mr, mg, mb, cz;
-            int mx, my;
-            if (USE_LDS) {
-                const ClusterRec r = recs[id];
-                mr = r.r; mg = r.g; mb = r.b; mx = r.x; my = r.y; cz = r.cz;
+    for (int n = 0; n < NS; n++) {
+        const CalcSet& cs = sets.s[n];
+        const kde_label_distance cur = cs.ld[p];
+        const int ccx = cur.l % g.cols, ccy = cur.l / g.cols;
+        float dist[16];
+        int lab[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int rx = ccx - 2 + (t & 3), ry = ccy - 2 + (t >> 2);
+            if (rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows) {
+                const int id = ry * g.cols + rx;
+                float mr, mg, mb, cz;
+                int mx, my;
+                if (USE_LDS) {
+                    const ClusterRec r = recs[n * nclusters + id];
+                    mr = r.r; mg = r.g; mb = r.b; mx = r.x; my = r.y; cz = r.cz;
+                } else {
+                    const kde_superpixel m = cs.mean[id];
+                    mr = (float)m.r; mg = (float)m.g; mb = (float)m.b; mx = m.x; my = m.y;
+                    cz = cs.centers[id].z;
+                }
+                const float e0 = c0 - mr, e1 = c1 - mg, e2 = c2 - mb;
+                const float color_distance = e0 * e0 + e1 * e1 + e2 * e2;
+                const float px = (float)(x - mx), py = (float)(y - my);
+                const float spatial_distance = sqrtf(px * px + py * py) * win2;
+                float depth_distance = 0.0f;
+                if (z > 50.0f && cz > 50.0f) depth_distance = fabsf(z - cz);
+                dist[t] = color_distance * cs.kc + spatial_distance * cs.ks + depth_distance * cs.kd;   // .cu:218
+                lab[t] = id;
             } else {
-                const kde_superpixel m = mean[id];
-                mr = (float)m.r; mg = (float)m.g; mb = (float)m.b; mx = m.x; my = m.y;
-                cz = centers[id].z;
-            }
-            const float e0 = c0 - mr, e1 = c1 - mg, e2 = c2 - mb;
-            const float color_distance = e0 * e0 + e1 * e1 + e2 * e2;
-            const float px = (float)(x - mx), py = (float)(y - my);
-            const float spatial_distance = sqrtf(px * px + py * py) * win2;
-            float depth_distance = 0.0f;
-            if (z > 50.0f && cz > 50.0f) depth_distance = fabsf(z - cz);
-            dist[t] = color_distance * kc + spatial_distance * ks + depth_distance * kd;   // .cu:218
-            lab[t] = id;
-        } else {
-            dist[t] = cur.d;   // .cu:221-224
-            lab[t] = cur.l;
-        }
-    }
-#pragma unroll
-    for (int step = 8; step >= 1; step >>= 1) {
-#pragma unroll
-        for (int t = 0; t < step; t++) {
-            if (dist[t] > dist[t + step]) {
-                lab[t] = lab[t + step];
-                dist[t] = dist[t + step];
+                dist[t] = cur.d;   // .cu:221-224
+                lab[t] = cur.l;
             }
         }
+#pragma unroll
+        for (int step = 8; step >= 1; step >>= 1) {
+#pragma unroll
+            for (int t = 0; t < step; t++) {
+                if (dist[t] > dist[t + step]) {
+                    lab[t] = lab[t + step];
+                    dist[t] = dist[t + step];
+                }
+            }
+        }
+        kde_label_distance o;
+        o.l = lab[0];
+        o.d = dist[0];
+        if (z < 50.0f && cs.depth_on) {   // .cu:308-312
+            o.l = -1;
+            o.d = 0.0f;
+        }
+        cs.ld[p] = o;
+        cs.labels[p] = o.l;
     }
-    kde_label_distance o;
-    o.l = lab[0];
-    o.d = dist[0];
-    if (z < 50.0f && depth_on) {   // .cu:308-312
-        o.l = -1;
-        o.d = 0.0f;
-    }
-    ld[p] = o;
-    labels[p] = o.l;
 }
 
 // ---- K8 analyzeClusters<256> (.cu:315-568) ---------------------------------------------------------
@@ -315,25 +332,54 @@ int launch_dasp_sample(const DaspGeom& g, const uint8_t* bgr, const kde_float3* 
     return KDE_OK;
 }
 
+static CalcSet make_set(const DaspGeom& g, kde_label_distance* ld, const kde_superpixel* mean, const kde_float3* centers,
+                        int32_t* labels, float color_sigma, float spatial_sigma, float depth_sigma)
+{
+    // host-side scalars formed exactly as .cu:209-218 does per thread
+    const float sum_sigma = spatial_sigma + color_sigma + depth_sigma;
+    const float rc = color_sigma / sum_sigma, rs = spatial_sigma / sum_sigma, rd = depth_sigma / sum_sigma;
+    CalcSet c;
+    c.ld = ld; c.mean = mean; c.centers = centers; c.labels = labels;
+    c.kc = rc * rc; c.ks = rs * rs; c.kd = rd * rd;
+    c.depth_on = depth_sigma != 0.0f ? 1 : 0;
+    return c;
+}
+
 int launch_dasp_calc_ld(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld,
                         const kde_superpixel* mean, const kde_float3* centers, int32_t* labels, float color_sigma,
                         float spatial_sigma, float depth_sigma, hipStream_t s)
 {
-    // host-side scalars formed exactly as .cu:209-218 does per thread
     const float half = (float)(g.wx + g.wy) / 2.0f;
     const float win2 = half * half;
-    const float sum_sigma = spatial_sigma + color_sigma + depth_sigma;
-    const float rc = color_sigma / sum_sigma, rs = spatial_sigma / sum_sigma, rd = depth_sigma / sum_sigma;
-    const float kc = rc * rc, ks = rs * rs, kd = rd * rd;
+    CalcSets<1> sets;
+    sets.s[0] = make_set(g, ld, mean, centers, labels, color_sigma, spatial_sigma, depth_sigma);
     const int nclusters = g.rows * g.cols;
     dim3 grid(ceil_div(g.width, 64), ceil_div(g.height, 4));
-    if (nclusters <= kMaxLdsClusters) {
-        hipLaunchKernelGGL(calc_ld_kernel<true>, grid, dim3(256), (size_t)nclusters * sizeof(ClusterRec), s, g, bgr, pts,
-                           ld, mean, centers, labels, kc, ks, kd, win2, depth_sigma != 0.0f ? 1 : 0);
-    } else {
-        hipLaunchKernelGGL(calc_ld_kernel<false>, grid, dim3(256), 0, s, g, bgr, pts, ld, mean, centers, labels, kc, ks,
-                           kd, win2, depth_sigma != 0.0f ? 1 : 0);
-    }
+    if (nclusters <= kMaxLdsClusters)
+        hipLaunchKernelGGL((calc_ld_kernel<1, true>), grid, dim3(256), (size_t)nclusters * sizeof(ClusterRec), s, g, bgr, pts, sets, win2);
+    else
+        hipLaunchKernelGGL((calc_ld_kernel<1, false>), grid, dim3(256), 0, s, g, bgr, pts, sets, win2);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+// both segmenters of a pipeline in one pass (see CalcSet)
+int launch_dasp_calc_ld_dual(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld_a,
+                             const kde_superpixel* mean_a, const kde_float3* centers_a, int32_t* labels_a,
+                             const float sig_a[3], kde_label_distance* ld_b, const kde_superpixel* mean_b,
+                             const kde_float3* centers_b, int32_t* labels_b, const float sig_b[3], hipStream_t s)
+{
+    const float half = (float)(g.wx + g.wy) / 2.0f;
+    const float win2 = half * half;
+    CalcSets<2> sets;
+    sets.s[0] = make_set(g, ld_a, mean_a, centers_a, labels_a, sig_a[0], sig_a[1], sig_a[2]);
+    sets.s[1] = make_set(g, ld_b, mean_b, centers_b, labels_b, sig_b[0], sig_b[1], sig_b[2]);
+    const int nclusters = g.rows * g.cols;
+    dim3 grid(ceil_div(g.width, 64), ceil_div(g.height, 4));
+    if (2 * nclusters <= kMaxLdsClusters)
+        hipLaunchKernelGGL((calc_ld_kernel<2, true>), grid, dim3(256), (size_t)2 * nclusters * sizeof(ClusterRec), s, g, bgr, pts, sets, win2);
+    else
+        hipLaunchKernelGGL((calc_ld_kernel<2, false>), grid, dim3(256), 0, s, g, bgr, pts, sets, win2);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }

@@ -804,8 +804,28 @@ struct Pipeline {
     int run(const float* depth, const kde_float3* pts, const uint8_t* bgr, float c1, float s1, float d1, float c2,
             float s2, float d2, int iters, void* stream)
     {
-        KDE_TRY(kde_dasp_segmentation(SP, bgr, pts, c1, s1, d1, iters, stream));
-        KDE_TRY(kde_dasp_segmentation(DASP, bgr, pts, c2, s2, d2, iters, stream));
+        KDE_REQUIRE(SP->set && DASP->set, "Process: SetParametor was not called");
+        KDE_REQUIRE(bgr && pts && depth, "Process: null argument");
+        // SP->Segmentation(...) and DASP->Segmentation(...) (RegionGrowingBilateralFilter.cpp:28-29) run on the same
+        // colour + cloud with the same grid, so they share the work that does not depend on the sigmas:
+        // sampleInitialClusters is computed once (its result is identical for both) and every assignment step
+        // labels both maps in one pass.  Per-object results are exactly those of two separate Segmentation calls.
+        hipStream_t s = as_stream(stream);
+        const DaspGeom& g = SP->g;
+        const size_t k = (size_t)g.rows * g.cols;
+        KDE_TRY(launch_dasp_init_ld(g, SP->ld.p, s));
+        KDE_TRY(launch_dasp_init_ld(g, DASP->ld.p, s));
+        KDE_TRY(launch_dasp_sample(g, bgr, pts, SP->mean.p, SP->centers.p, s));
+        KDE_HIP_TRY(hipMemcpyAsync(DASP->mean.p, SP->mean.p, k * sizeof(kde_superpixel), hipMemcpyDeviceToDevice, s));
+        KDE_HIP_TRY(hipMemcpyAsync(DASP->centers.p, SP->centers.p, k * sizeof(kde_float3), hipMemcpyDeviceToDevice, s));
+        const float sa[3] = {c1, s1, d1}, sb[3] = {c2, s2, d2};
+        for (int i = 0; i < iters; i++) {
+            KDE_TRY(launch_dasp_calc_ld_dual(g, bgr, pts, SP->ld.p, SP->mean.p, SP->centers.p, SP->labels.p, sa, DASP->ld.p,
+                                             DASP->mean.p, DASP->centers.p, DASP->labels.p, sb, s));
+            if (i == iters - 1) break;   // the trailing analyzeClusters is dead for the private segmenters
+            KDE_TRY(launch_dasp_analyze(g, bgr, pts, SP->ld.p, SP->mean.p, SP->centers.p, SP->intr.p, s));
+            KDE_TRY(launch_dasp_analyze(g, bgr, pts, DASP->ld.p, DASP->mean.p, DASP->centers.p, DASP->intr.p, s));
+        }
         return kde_ers_edge_refining(ERS, SP->labels.p, DASP->labels.p, depth, bgr, stream);
     }
 };

@@ -239,3 +239,50 @@ def test_spdsr_tail_degenerate_clusters(torch_cuda, F, oracle, synth):
     assert np.array_equal(nd[marker, :3], nd_ref[marker, :3])
     # (the flat patch makes K10 emit NaNs (Q6); they propagate into the moments of their cluster on both sides)
     assert np.allclose(nd[~marker], nd_ref[~marker], rtol=2e-5, atol=2e-6, equal_nan=True)
+
+
+def test_chain_is_hip_graph_capturable(torch_cuda, F, oracle, synth, frame):
+    """every entry point is launch-only (no allocation / synchronisation), so a launch-bound single-frame
+    chain can be captured once into a hipGraph and replayed (cdna_hip_programming.md Guideline 9)."""
+    t = torch_cuda
+    w, h = 640, 480
+    bgr, depth = frame(13, w, h)
+    K = synth.intrinsics(w, h)
+    conv = F.DimensionConvertor(); conv.setCameraParameters(K, w, h)
+    jbf = F.JointBilateralFilter(w, h)
+    rg = F.RegionGrowingBilateralFilter(w, h); rg.SetParametor(15, 20, K)
+    color, d = dev(t, bgr), dev(t, depth)
+    pts = t.empty((h, w, 3), dtype=t.float32, device="cuda")
+    filt = jbf.getFiltered_Device()
+
+    def chain():
+        jbf.Process(d, color)
+        conv.projectiveToReal(filt, pts)
+        rg.Process(filt, pts, color)
+
+    chain()
+    t.cuda.synchronize()
+    eager_depth = rg.getRefinedDepth_Device().clone()
+    eager_labels = rg.getRefinedLabels_Device().clone()
+    side = t.cuda.Stream()
+    side.wait_stream(t.cuda.current_stream())
+    with t.cuda.stream(side):
+        chain()                                        # warm-up on the capture stream
+        g = t.cuda.CUDAGraph()
+        with t.cuda.graph(g, stream=side):
+            chain()
+    t.cuda.current_stream().wait_stream(side)
+    rg.getRefinedDepth_Device().zero_()
+    d2 = dev(t, frame(15, w, h)[1])                    # new input through the same device buffer
+    d.copy_(d2)
+    g.replay()
+    t.cuda.synchronize()
+    jbf2 = F.JointBilateralFilter(w, h)
+    rg2 = F.RegionGrowingBilateralFilter(w, h); rg2.SetParametor(15, 20, K)
+    jbf2.Process(d, color)
+    p2 = t.empty_like(pts)
+    conv.projectiveToReal(jbf2.getFiltered_Device(), p2)
+    rg2.Process(jbf2.getFiltered_Device(), p2, color)
+    assert t.equal(rg.getRefinedLabels_Device(), rg2.getRefinedLabels_Device())
+    assert t.equal(t.nan_to_num(rg.getRefinedDepth_Device()), t.nan_to_num(rg2.getRefinedDepth_Device()))
+    assert not t.equal(rg.getRefinedLabels_Device(), eager_labels) or not t.equal(t.nan_to_num(eager_depth), t.nan_to_num(rg.getRefinedDepth_Device()))

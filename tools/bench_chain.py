@@ -56,6 +56,16 @@ def main():
         rg.Process(filt, pts, color)           # K5-K10
     res["chain_ms"] = timed(torch, chain, a.iters)
     res["chain_mpix_s"] = px / res["chain_ms"] / 1e3
+    # the same chain captured once into a hipGraph and replayed (launch-bound at small frames)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        chain()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            chain()
+    torch.cuda.current_stream().wait_stream(side)
+    res["chain_graph_ms"] = timed(torch, g.replay, a.iters)
 
     # streaming feeders on a batch (HBM-bound): algorithmic bytes / time against 8 TB/s
     n = a.stream_frames
