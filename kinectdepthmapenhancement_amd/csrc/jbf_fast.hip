@@ -247,13 +247,16 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     // and RA >= R is chosen so that o is a multiple of 4: the loader then moves 4-pixel groups with
     // 16-byte depth loads and 12-byte colour loads that are aligned in the image.
     // VL = false keeps the plain geometry (RA = R, one pixel per loader iteration) for A/B measurements.
-    constexpr int S1 = VL ? (R & 1) : 0;
-    constexpr int RA = !VL ? R : (S1 ? ((R - 3 + 3) / 4 * 4 + 3) : ((R + 3) / 4 * 4));
+    // (S1 = 1 would shift the tiles one column left for odd radii to keep the pairs 8-byte aligned; measured
+    //  slower than unaligned pair reads because of the extra, nearly empty tile column it costs)
+    constexpr int S1 = 0;
+    constexpr int RA = !VL ? R : ((R + 3) / 4 * 4);
+    constexpr bool ALIGNED = ((RA - R) % 2) == 0;     // row segments start on an even LDS column
     constexpr int P = VL ? (RA + TW + R + 3) / 4 * 4 : (TW + 2 * R);   // row pitch in dwords
     constexpr int G = P / 4;                          // 4-pixel groups per row
     constexpr int SEGP = NP + R;                      // aligned pairs in the row segment of a thread
     constexpr int HALF = (WIN - 1) / 2;
-    static_assert(RA >= R && (RA - R) % 2 == 0 && P % 2 == 0 && (!VL || ((RA + S1) % 4 == 0 && TW % 4 == 0)), "tile geometry");
+    static_assert(RA >= R && P % 2 == 0 && (!VL || ((RA + S1) % 4 == 0 && TW % 4 == 0)), "tile geometry");
     __shared__ __attribute__((aligned(16))) float s_d[LH * P];
     __shared__ __attribute__((aligned(16))) uint32_t s_c[LH * P];
     __shared__ __attribute__((aligned(16))) uint32_t s_n[LH * P];
@@ -395,9 +398,9 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         const int rb = (ty + i) * P + sx;
 #pragma unroll
         for (int m = 0; m < SEGP; m++) {
-            dp[m] = *reinterpret_cast<const f2*>(&s_d[rb + 2 * m]);
-            cp[m] = *reinterpret_cast<const u2*>(&s_c[rb + 2 * m]);
-            np[m] = *reinterpret_cast<const u2*>(&s_n[rb + 2 * m]);
+            dp[m] = ALIGNED ? *reinterpret_cast<const f2*>(&s_d[rb + 2 * m]) : f2{s_d[rb + 2 * m], s_d[rb + 2 * m + 1]};
+            cp[m] = ALIGNED ? *reinterpret_cast<const u2*>(&s_c[rb + 2 * m]) : u2{s_c[rb + 2 * m], s_c[rb + 2 * m + 1]};
+            np[m] = ALIGNED ? *reinterpret_cast<const u2*>(&s_n[rb + 2 * m]) : u2{s_n[rb + 2 * m], s_n[rb + 2 * m + 1]};
         }
 #pragma unroll
         for (int pp = 0; pp < NP; pp++) {
@@ -434,10 +437,10 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         const int rb = (ty + i) * P + sx;
 #pragma unroll
         for (int m = 0; m < SEGP; m++) {
-            dp[m] = *reinterpret_cast<const f2*>(&s_d[rb + 2 * m]);
+            dp[m] = ALIGNED ? *reinterpret_cast<const f2*>(&s_d[rb + 2 * m]) : f2{s_d[rb + 2 * m], s_d[rb + 2 * m + 1]};
             if (!CACHE) {
-                cp[m] = *reinterpret_cast<const u2*>(&s_c[rb + 2 * m]);
-                np[m] = *reinterpret_cast<const u2*>(&s_n[rb + 2 * m]);
+                cp[m] = ALIGNED ? *reinterpret_cast<const u2*>(&s_c[rb + 2 * m]) : u2{s_c[rb + 2 * m], s_c[rb + 2 * m + 1]};
+                np[m] = ALIGNED ? *reinterpret_cast<const u2*>(&s_n[rb + 2 * m]) : u2{s_n[rb + 2 * m], s_n[rb + 2 * m + 1]};
             }
         }
 #pragma unroll
@@ -479,7 +482,7 @@ template <int WIN, int NP, int BX, int BY, bool CACHE, bool VL>
 int launch_pk_variant(const JbfLaunch& l, const FastArgs& fa, bool cskip, hipStream_t s)
 {
     FastArgs a = fa;
-    a.tiles_x = ceil_div(l.width + (VL ? ((WIN / 2) & 1) : 0), BX * NP * 2);   // VL tiles start one column early for odd radii
+    a.tiles_x = ceil_div(l.width, BX * NP * 2);
     a.tiles_y = ceil_div(l.height, BY);
     const long long blocks = (long long)a.tiles_x * a.tiles_y * l.n;
     if (blocks > 0x7fffffffLL) return fail(KDE_ERR_INVALID, "jbf: batch too large for one launch");
