@@ -8,11 +8,13 @@
 //     float 2^23 + 2^18 - |b|^2 + 2 a.b, i.e. no int->float convert;
 //   * weights live in the log2 domain: arg1 = log2(S_ij) - kc*cd, arg2 = arg1 - kd*(d_q - avg)^2, one
 //     v_exp_f32 per tap and pass; pass-1 arguments stay in registers for pass 2 (windows <= 7);
-//   * taps that are invalid (depth <= 50 mm or outside the image) carry a bias of 0xFF000000 (-1.7e38),
-//     which drives the argument to -1.7e38*kc and the weight to exactly 0 with no branch or select;
+//   * taps that are invalid (depth <= 50 mm or outside the image) cost no branch or select: the scalar kernels
+//     give them a bias of 0xFF000000 (-1.7e38, weight exactly 0), the packed kernels multiply their weight by
+//     v = clamp(2 d) = 0 inside the accumulating fma;
 //   * the reference's "a factor that underflowed to exactly 0 is not multiplied in" rule (Q1) is decided
 //     on the ARGUMENT (integer colour distance / |d_q - avg|) against host-computed thresholds, so it does
-//     not depend on how small numbers are rounded by the exp hardware;
+//     not depend on how small numbers are rounded by the exp hardware; in the packed kernels the decision is
+//     a {0,1} mask produced by the VOP3P clamp bit (no v_cmp / v_cndmask);
 //   * each thread owns PX horizontally adjacent pixels and walks the window row by row from registers.
 // Depth + guide + |b|^2 tiles (with halo) are staged once per workgroup in LDS; the workgroup->tile map
 // keeps each XCD on a contiguous band of tiles so halos are shared in that XCD's L2.
@@ -35,6 +37,7 @@ struct FastArgs {
     float kc;        // log2(e) / (2 sigma_c^2)
     float sd;        // sqrt(log2(e) / (2 sigma_d^2))
     float t_skip;    // depth factor skipped when |d_q - avg| * sd >= t_skip
+    float t2_skip;   // t_skip^2 (3e38 when nothing is skipped) for the packed-arithmetic form of the rule
     int cd_skip;     // colour factor skipped when cd >= cd_skip
     int vec4;        // width % 4 == 0 and 16-byte aligned frames: the packed kernels load 4-pixel groups
     // log2 of the spatial table (zeros of the table -> factor skipped -> log2 = 0).  Scalar kernels read
@@ -225,14 +228,29 @@ __global__ __launch_bounds__(BX* BY) void jbf_fast_kernel(const FastArgs a)
 //    leftover:            p0 tap 1   = hi(m0), p1 tap WIN-2 = lo(m1)     (one v_pk_mov_b32)
 // The spatial weight costs nothing per tap: log2(S[i][j]) of the unit's two taps is the (SGPR-pair) addend of
 // the argument fma.
-// Per tap: pass 1 = v_dot4 + v_lshl_add + v_exp (8 cycles) + 2 packed ops (4 per unit: add, fma, fma, add);
-// pass 2 = v_cmp + v_cndmask + v_exp + 2.5 packed ops (5 per unit: add, mul, fma, fma, add).
+// Per unit (= 2 taps), window 11, in 4-cycle issue slots (v_exp_f32 counts 2):
+//   pass 1: 2 v_dot4 + 2 v_lshl_add + 2 v_exp + 6 packed (-cd, mask, mask*kc, arg fma, 2 accumulating fma) = 14.3
+//   pass 2: the same argument (8) + 2 v_exp + 8 packed (d-avg, *sd, T2-t^2, mask, t*mask, arg fma, 2 acc.)   = 20.3
+// (the select form of the Q1 rules cost 17 + 24: profiles/r01_sweep_k1_clamp_form.log has the A/B.)
 // ---------------------------------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 bcast(float v) { return f2{v, v}; }
+// packed add / multiply with the VOP3P clamp bit: the result is clamped to [0, 1] (NaN -> 0, DX10_CLAMP is on)
+__device__ __forceinline__ f2 pk_add_clamp(f2 a, f2 b)
+{
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f2 pk_mul_clamp(f2 a, f2 b)
+{
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 template <int WIN, int NP, int BX, int BY, bool CACHE, bool CSKIP, bool VL>
 __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
             const bool valid = d > 50.0f;
             s_d[i] = valid ? d : 0.0f;
             s_c[i] = c;
-            s_n[i] = valid ? (kMagic + kOff) - dot4(c, c, 0) : kInvalidBias;
+            s_n[i] = (kMagic + kOff) - dot4(c, c, 0);
         }
     }
     for (int g = tid; VL && g < G * LH; g += NT) {
@@ -328,7 +346,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         for (int k = 0; k < 4; k++) {
             const bool valid = d[k] > 50.0f;
             d[k] = valid ? d[k] : 0.0f;
-            nn[k] = valid ? (kMagic + kOff) - dot4(c[k], c[k], 0) : kInvalidBias;
+            nn[k] = (kMagic + kOff) - dot4(c[k], c[k], 0);
         }
         const int li = ly * P + 4 * gi;
         *reinterpret_cast<float4*>(&s_d[li]) = make_float4(d[0], d[1], d[2], d[3]);
@@ -342,7 +360,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     if (xb >= a.width || y >= a.height) return;
     const int sx = RA - R + tx * PX;       // LDS column of this thread's first window column (even)
 
-    uint32_t cc[PX], thrU[PX];
+    uint32_t cc[PX];
     f2 negC[NP];          // -(2^23 + 2^18 + |a|^2): F + negC = -cd exactly (integers < 2^24)
 #pragma unroll
     for (int pp = 0; pp < NP; pp++) {
@@ -352,7 +370,6 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
             cc[k] = s_c[(ty + R) * P + sx + R + k];
             const uint32_t na = dot4(cc[k], cc[k], 0);
             negC[pp][h] = -(kBiasF + (float)na);
-            thrU[k] = CSKIP ? (kMagic + kOff) + na - (uint32_t)a.cd_skip : 0;
         }
     }
 
@@ -362,6 +379,14 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     f2 wsum[NP], wgt[NP];
 #pragma unroll
     for (int pp = 0; pp < NP; pp++) wsum[pp] = wgt[pp] = bcast(0.0f);
+
+    // Q1 rules as packed arithmetic on {0,1} masks made by the clamp bit:
+    //   colour: m = clamp(cd_skip - cd) is 1 for cd < cd_skip and 0 otherwise (integers), a1 = fma(-cd, kc*m, ls)
+    //   depth:  q = T2 - t^2 (one rounding, sign exact), m = clamp(q * 2^100), a2 = fma(-(t*m), t, a1)
+    //   invalid taps: colour code and depth 0 stay finite, and the tap enters the sums with v = clamp(2 d) = 0
+    const f2 Tc = bcast((float)a.cd_skip);
+    const f2 T2 = bcast(a.t2_skip);
+    const f2 kBig = bcast(0x1p100f);
 
     // argument (log2 domain, without the row factor) of S*cf for the two taps of unit u of pair pp
     auto unit_arg = [&](const u2* cp, const u2* np, int pp, int i, int u) -> f2 {
@@ -379,12 +404,8 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         // -cd exactly, then ONE rounding in the fma: a1 = log2(S[i][j]) - kc*cd
         const f2 ncd = f2{__uint_as_float(u0), __uint_as_float(u1)} + negC[pp];
         const f2 lsj = *reinterpret_cast<const f2*>(&a.tab[(i * WIN + u) * 2]);
-        f2 a1 = pk_fma(ncd, kc2, lsj);
-        if (CSKIP) {   // Q1: an underflowed colour factor is skipped (invalid codes compare above the threshold)
-            a1.x = (u0 <= thrU[2 * pp]) ? lsj.x : a1.x;
-            a1.y = (u1 <= thrU[2 * pp + 1]) ? lsj.y : a1.y;
-        }
-        return a1;
+        if (CSKIP) return pk_fma(ncd, pk_add_clamp(ncd, Tc) * kc2, lsj);   // Q1: underflowed colour factor skipped
+        return pk_fma(ncd, kc2, lsj);
     };
     auto unit_depth = [&](const f2* dp, int pp, int u) -> f2 {
         if (u <= HALF) return dp[pp + u];
@@ -393,7 +414,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     };
 
     auto pass1_row = [&](int i) {
-        f2 dp[SEGP];
+        f2 dp[SEGP], vp[SEGP];
         u2 cp[SEGP], np[SEGP];
         const int rb = (ty + i) * P + sx;
 #pragma unroll
@@ -401,6 +422,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
             dp[m] = ALIGNED ? *reinterpret_cast<const f2*>(&s_d[rb + 2 * m]) : f2{s_d[rb + 2 * m], s_d[rb + 2 * m + 1]};
             cp[m] = ALIGNED ? *reinterpret_cast<const u2*>(&s_c[rb + 2 * m]) : u2{s_c[rb + 2 * m], s_c[rb + 2 * m + 1]};
             np[m] = ALIGNED ? *reinterpret_cast<const u2*>(&s_n[rb + 2 * m]) : u2{s_n[rb + 2 * m], s_n[rb + 2 * m + 1]};
+            vp[m] = pk_add_clamp(dp[m], dp[m]);      // 1 for a valid tap (d > 50), 0 for d == 0
         }
 #pragma unroll
         for (int pp = 0; pp < NP; pp++) {
@@ -410,7 +432,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
                 if (CACHE) arg[(i * NP + pp) * WIN + u] = a1;
                 const f2 f = f2{__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
                 wsum[pp] = pk_fma(unit_depth(dp, pp, u), f, wsum[pp]);
-                wgt[pp] = wgt[pp] + f;
+                wgt[pp] = pk_fma(unit_depth(vp, pp, u), f, wgt[pp]);
             }
         }
     };
@@ -432,12 +454,13 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     }
 
     auto pass2_row = [&](int i) {
-        f2 dp[SEGP];
+        f2 dp[SEGP], vp[SEGP];
         u2 cp[SEGP], np[SEGP];
         const int rb = (ty + i) * P + sx;
 #pragma unroll
         for (int m = 0; m < SEGP; m++) {
             dp[m] = ALIGNED ? *reinterpret_cast<const f2*>(&s_d[rb + 2 * m]) : f2{s_d[rb + 2 * m], s_d[rb + 2 * m + 1]};
+            vp[m] = pk_add_clamp(dp[m], dp[m]);
             if (!CACHE) {
                 cp[m] = ALIGNED ? *reinterpret_cast<const u2*>(&s_c[rb + 2 * m]) : u2{s_c[rb + 2 * m], s_c[rb + 2 * m + 1]};
                 np[m] = ALIGNED ? *reinterpret_cast<const u2*>(&s_n[rb + 2 * m]) : u2{s_n[rb + 2 * m], s_n[rb + 2 * m + 1]};
@@ -450,12 +473,11 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
                 const f2 a1 = CACHE ? arg[(i * NP + pp) * WIN + u] : unit_arg(cp, np, pp, i, u);
                 const f2 dq = unit_depth(dp, pp, u);
                 const f2 t = (dq - c2[pp]) * bcast(a.sd);    // subtract first: see the scalar kernel
-                f2 a2 = pk_fma(-t, t, a1);
-                a2.x = (__builtin_fabsf(t.x) >= a.t_skip) ? a1.x : a2.x;   // Q1: underflowed depth factor skipped
-                a2.y = (__builtin_fabsf(t.y) >= a.t_skip) ? a1.y : a2.y;
+                const f2 m = pk_mul_clamp(pk_fma(-t, t, T2), kBig);        // Q1: underflowed depth factor skipped
+                const f2 a2 = pk_fma(-(t * m), t, a1);
                 const f2 f = f2{__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
                 num[pp] = pk_fma(dq, f, num[pp]);
-                den[pp] = den[pp] + f;
+                den[pp] = pk_fma(unit_depth(vp, pp, u), f, den[pp]);
             }
         }
     };
@@ -589,6 +611,7 @@ int launch_jbf_fast(const JbfLaunch& l, int variant, const float* table_host, hi
     a.kc = (float)(log2e / (double)l.color_den);
     a.sd = (float)std::sqrt(log2e / (double)l.depth_den);
     a.t_skip = std::isinf(l.d2_skip) ? INFINITY : (float)(std::sqrt((double)l.d2_skip) * std::sqrt(log2e / (double)l.depth_den));
+    a.t2_skip = std::isinf(a.t_skip) ? 3.0e38f : a.t_skip * a.t_skip;
     a.cd_skip = l.cd_skip;
     a.vec4 = (l.width % 4 == 0) && ((reinterpret_cast<uintptr_t>(l.depth) & 15u) == 0) &&
              ((reinterpret_cast<uintptr_t>(l.guide) & 3u) == 0);
