@@ -151,6 +151,7 @@ struct PreDev {
 };
 
 constexpr int kPreBX = 16, kPreBY = 16, kPrePX = 4;
+typedef float pre_f2 __attribute__((ext_vector_type(2)));
 constexpr int kPreTW = kPreBX * kPrePX, kPreTH = kPreBY;
 
 template <int R>
@@ -190,28 +191,28 @@ __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
         const int xb = x0 + tx * kPrePX, y = y0 + ty;
         if (xb >= a.width || y >= a.height) continue;
 
+        // (b, g) accumulate as one packed pair (v_pk_fma_f32, same roundings as two fma); packing (r, weight sum)
+        // as well costs 8 more VGPRs for the {r, 1.0} operands and drops the kernel to 3 waves/SIMD
         uint32_t cc[kPrePX];
-        float s0[kPrePX], s1[kPrePX], s2[kPrePX], sum2[kPrePX];
+        pre_f2 sbg[kPrePX], srw[kPrePX];
 #pragma unroll
         for (int k = 0; k < kPrePX; k++) {
             cc[k] = sc[(ty + R) * LW + tx * kPrePX + R + k];
-            s0[k] = s1[k] = s2[k] = sum2[k] = 0.0f;
+            sbg[k] = srw[k] = pre_f2{0.0f, 0.0f};
         }
 #pragma unroll
         for (int dy = -R; dy <= R; dy++) {
             uint32_t v[SEG];
-            float f0[SEG], f1[SEG], f2[SEG];
+            pre_f2 fbg[SEG];
+            float fr[SEG];
 #pragma unroll
             for (int q = 0; q < SEG; q++) {
                 v[q] = sc[(ty + R + dy) * LW + tx * kPrePX + q];
-                f0[q] = (float)(v[q] & 0xffu);
-                f1[q] = (float)((v[q] >> 8) & 0xffu);
-                f2[q] = (float)((v[q] >> 16) & 0xffu);
+                fbg[q] = pre_f2{(float)(v[q] & 0xffu), (float)((v[q] >> 8) & 0xffu)};
+                fr[q] = (float)((v[q] >> 16) & 0xffu);
             }
 #pragma unroll
             for (int dx = -R; dx <= R; dx++) {
-                constexpr int dummy = 0;
-                (void)dummy;
                 const int space2 = dx * dx + dy * dy;
                 if (space2 > R * R) continue;        // same tap order as the reference kernel: cy outer, cx inner
 #pragma unroll
@@ -219,10 +220,10 @@ __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
                     const int q = k + R + dx;
                     const uint32_t n1 = __builtin_amdgcn_sad_u8(v[q], cc[k], 0u);   // |db| + |dg| + |dr|
                     const float w = lut[space2 * 766 + n1];
-                    s0[k] = __builtin_fmaf(w, f0[q], s0[k]);
-                    s1[k] = __builtin_fmaf(w, f1[q], s1[k]);
-                    s2[k] = __builtin_fmaf(w, f2[q], s2[k]);
-                    sum2[k] = sum2[k] + w;
+                    const pre_f2 ww = pre_f2{w, w};
+                    sbg[k] = __builtin_elementwise_fma(ww, fbg[q], sbg[k]);
+                    srw[k].x = __builtin_fmaf(w, fr[q], srw[k].x);
+                    srw[k].y += w;
                 }
             }
         }
@@ -231,10 +232,30 @@ __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
             if (x >= 255.0f) return 255u;
             return (uint32_t)rintf(x);
         };
+        // The reference divides (IEEE) and rounds half-to-even to u8.  rcp + one Newton step is within 1 ulp
+        // (< 1.6e-5 below 256) of the quotient, which rounds to the same integer unless the quotient sits within
+        // that distance of k + 0.5; those (rare) lanes take the IEEE division, so the byte is the reference's.
         uint32_t px[kPrePX];
 #pragma unroll
-        for (int k = 0; k < kPrePX; k++)
-            px[k] = sat(s0[k] / sum2[k]) | (sat(s1[k] / sum2[k]) << 8) | (sat(s2[k] / sum2[k]) << 16);
+        for (int k = 0; k < kPrePX; k++) {
+            const float den = srw[k].y;
+            const float r = __builtin_amdgcn_rcpf(den);
+            float q[3] = {sbg[k].x, sbg[k].y, srw[k].x};
+            bool ambiguous = false;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float num = q[c];
+                const float q0 = num * r;
+                q[c] = __builtin_fmaf(__builtin_fmaf(-den, q0, num), r, q0);
+                ambiguous |= !(__builtin_fabsf(__builtin_fabsf(q[c] - rintf(q[c])) - 0.5f) > 1.0e-4f);   // NaN -> exact path
+            }
+            if (ambiguous) {
+                q[0] = sbg[k].x / den;
+                q[1] = sbg[k].y / den;
+                q[2] = srw[k].x / den;
+            }
+            px[k] = sat(q[0]) | (sat(q[1]) << 8) | (sat(q[2]) << 16);
+        }
         uint8_t* o = a.dst + (frame + (size_t)y * a.width + xb) * 3;
         if ((a.width & 3) == 0 && xb + 3 < a.width && (reinterpret_cast<uintptr_t>(a.dst) & 3u) == 0) {
             uint32_t* ow = reinterpret_cast<uint32_t*>(o);                  // 4 pixels = 12 bytes = 3 dwords
@@ -368,8 +389,29 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
     d.tiles_y = ceil_div(a.height, kPreTH);
     const long long total = (long long)d.tiles_x * d.tiles_y * a.n;
     if (total > 0x7fffffffLL) return fail(KDE_ERR_INVALID, "presmooth: batch too large for one launch");
-    // persistent grid: 256 CUs x 4 workgroups (20.7 KB of LDS each), fewer if there are fewer tiles
-    const unsigned grid = (unsigned)(total < 1024 ? total : 1024);
+    // persistent grid: every CU filled to the occupancy the variant reaches (LDS table + VGPRs), no second wave
+    auto resident = [](auto kernel) -> long long {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kPreBX * kPreBY, 0) != hipSuccess ||
+            cus <= 0 || per_cu <= 0) {
+            (void)hipGetLastError();
+            return 256;
+        }
+        return (long long)cus * per_cu;
+    };
+    static long long slots[5] = {0, 0, 0, 0, 0};
+    if (a.radius >= 1 && a.radius <= 4 && slots[a.radius] == 0) {
+        switch (a.radius) {
+            case 1: slots[1] = resident(presmooth_kernel<1>); break;
+            case 2: slots[2] = resident(presmooth_kernel<2>); break;
+            case 3: slots[3] = resident(presmooth_kernel<3>); break;
+            default: slots[4] = resident(presmooth_kernel<4>); break;
+        }
+    }
+    const long long cap = (a.radius >= 1 && a.radius <= 4) ? slots[a.radius] : 256;
+    const unsigned grid = (unsigned)(total < cap ? total : cap);
     switch (a.radius) {
         case 1: hipLaunchKernelGGL(presmooth_kernel<1>, dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
         case 2: hipLaunchKernelGGL(presmooth_kernel<2>, dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collects the profiling evidence of a round on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh <tag>     ->  gpurun_out/<tag>/...
+# 1. PMC passes (one counter group each, no tracing domains mixed in) -> pmc_traffic.json (also written into
+#    profiles/ of the box copy so that the bench lines below carry the traffic / VALU figures of THIS build)
+# 2. rocprofv3 --kernel-trace --stats over the default bench command
+# 3. the plain bench line
+set -eo pipefail
+TAG=${1:-final}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+SHORT="bench.py --steps 3 --warmup 1 --cpu-seconds 0"
+rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc/fetch" -o fetch -- python3 $SHORT > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc/write" -o write -- python3 $SHORT > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE -d "$OUT/pmc/sq" -o sq -- python3 $SHORT --no-extra > "$OUT/pmc_sq.log" 2>&1
+python3 tools/collect_pmc.py --dir "$OUT/pmc" --out "$OUT/pmc_traffic.json" 2> "$OUT/pmc_summary.log"
+cp "$OUT/pmc_traffic.json" profiles/pmc_traffic.json
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- python3 bench.py --cpu-seconds 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err"
+python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+find "$OUT/pmc" -name "*.csv" ! -name "*counter_collection.csv" -delete
+cat "$OUT/pmc_summary.log" "$OUT/bench.json"
