@@ -95,6 +95,7 @@ SIGNATURES = {
     "kde_ers_create": (_i, [_pp, _i, _i]),
     "kde_ers_destroy": (_i, [_vp]),
     "kde_ers_edge_refining": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "kde_ers_set_variant": (_i, [_vp, _i]),
     "kde_ers_stage_edge_depth_device": (_i, [_vp, _pp]),
     "kde_ers_refined_labels_device": (_i, [_vp, _pp]),
     "kde_ers_refined_depth_device": (_i, [_vp, _pp]),

@@ -86,6 +86,122 @@ __global__ __launch_bounds__(256) void edge_phase_kernel(int width, int height, 
 }
 
 // -------------------------------------------------------------------------------------------------
+// K9, one phase, LDS-staged.  The rule above is a chain of DEPENDENT reads along the scan line (boundary test,
+// outward search, depth cascade): from global memory that is ~40 serial L2 round trips per wave.  Here the
+// labels / colour labels / depth of the tile plus a halo of (window/2 + 3) scan positions are staged once and
+// the same rule runs on LDS.  Tile: DIR 0 = 64 scan positions x 4 lines, DIR 1 = SCAN1 scan positions x 64
+// lines (each thread owns SCAN1/4 of them); the 64-wide axis is always x, so global accesses stay coalesced.
+// -------------------------------------------------------------------------------------------------
+constexpr int kEdgeScan1 = 16;
+
+template <int DIR>
+__global__ __launch_bounds__(256) void edge_phase_lds_kernel(int width, int height, int window,
+                                                            const int32_t* __restrict__ color_labels,
+                                                            const int32_t* __restrict__ L0, const float* __restrict__ D0,
+                                                            int32_t* __restrict__ L1, float* __restrict__ D1)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char edge_smem[];
+    constexpr int SCAN = DIR == 0 ? 64 : kEdgeScan1;
+    constexpr int LINES = DIR == 0 ? 4 : 64;
+    const int half = window / 2, H = half + 3;
+    const int ext = SCAN + 2 * H;
+    int32_t* sL = reinterpret_cast<int32_t*>(edge_smem);
+    int32_t* sC = sL + ext * LINES;
+    float* sD = reinterpret_cast<float*>(sC + ext * LINES);
+
+    const int tid = threadIdx.x;
+    const int scan0 = DIR == 0 ? blockIdx.x * 64 : blockIdx.y * kEdgeScan1;
+    const int line0 = DIR == 0 ? blockIdx.y * 4 : blockIdx.x * 64;
+    const int len = DIR == 0 ? width : height;
+    const int nlines = DIR == 0 ? height : width;
+    // LDS layout: DIR 0 [line][k], DIR 1 [k][line] -- x is the fastest index of both the tile and the image
+    for (int i = tid; i < ext * LINES; i += 256) {
+        int k, line;
+        if (DIR == 0) {
+            line = i / ext;
+            k = i - line * ext;
+        } else {
+            k = i / LINES;
+            line = i - k * LINES;
+        }
+        const int gk = scan0 - H + k, gl = line0 + line;
+        int32_t l = 0, c = 0;
+        float d = 0.0f;
+        if (gk >= 0 && gk < len && gl < nlines) {
+            const size_t q = DIR == 0 ? (size_t)gl * width + gk : (size_t)gk * width + gl;
+            l = L0[q];
+            c = color_labels[q];
+            d = D0[q];
+        }
+        sL[i] = l;
+        sC[i] = c;
+        sD[i] = d;
+    }
+    __syncthreads();
+
+    const int line = DIR == 0 ? (tid >> 6) : (tid & 63);
+    if (line0 + line >= nlines) return;
+    const int kstride = DIR == 0 ? 1 : LINES;
+    const int lbase = (DIR == 0 ? line * ext : line) + (H - scan0) * kstride;
+#define AT(arr, k) ((arr)[lbase + (k) * kstride])
+    constexpr int PER = DIR == 0 ? 1 : kEdgeScan1 / 4;
+#pragma unroll 1
+    for (int r = 0; r < PER; r++) {
+        const int pos = scan0 + (DIR == 0 ? (tid & 63) : (tid >> 6) + 4 * r);
+        if (pos >= len) continue;
+        int out_label = AT(sL, pos);
+        bool have_label = false;
+        bool zero = false;
+        for (int s = pos + 2; s >= pos - 2; s--) {
+            if (s < 0 || s + 1 >= len) continue;
+            if (AT(sL, s) == AT(sL, s + 1)) continue;
+            const int cur = AT(sC, s);
+            int branch = 0, tp = 0;
+            for (int d = 1; d <= half && branch == 0; d++) {
+                if (s - d < 0 && s + d >= len) break;
+                if (s - d >= 0 && AT(sC, s - d) != cur) {
+                    branch = 1;
+                    tp = s - d;
+                } else if (s + d < len && AT(sC, s + d) != cur) {
+                    branch = 2;
+                    tp = s + d;
+                }
+            }
+            if (branch == 1) {
+                if (pos >= tp + 1 && pos <= s) {
+                    if (!have_label) {
+                        out_label = AT(sL, s + 1);
+                        have_label = true;
+                    }
+                    const float dp = AT(sD, pos);
+                    if (fabsf(dp - AT(sD, pos + 1)) > dp * 0.1f) zero = true;
+                }
+            } else if (branch == 2) {
+                if (pos >= s + 1 && pos <= tp - 1) {
+                    if (!have_label) {
+                        out_label = AT(sL, s);
+                        have_label = true;
+                    }
+                    float prev = AT(sD, s);
+                    bool z = false;
+                    for (int i = s + 1; i <= pos; i++) {
+                        float c = AT(sD, i);
+                        z = fabsf(c - prev) > c * 0.1f;
+                        if (z) c = 0.0f;
+                        prev = c;
+                    }
+                    if (z) zero = true;
+                }
+            }
+        }
+        const size_t q = DIR == 0 ? (size_t)(line0 + line) * width + pos : (size_t)pos * width + (line0 + line);
+        L1[q] = out_label;
+        D1[q] = zero ? 0.0f : AT(sD, pos);
+    }
+#undef AT
+}
+
+// -------------------------------------------------------------------------------------------------
 // K10 depthmap_enhancement — three passes over a (window x window) neighbourhood staged in LDS.
 // -------------------------------------------------------------------------------------------------
 constexpr int kTileX = 32, kTileY = 8, kThreads = 256;
@@ -376,11 +492,327 @@ __global__ __launch_bounds__(kThreads) void enhance7_kernel(const Enh7Dev a)
     a.out[p] = result;
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// K10, packed-pair form of enhance7_kernel (same semantics, same tolerance): every float add / mul / fma works
+// on a PAIR of horizontally adjacent pixels with v_pk_*_f32, and every per-tap decision is a {0,1} mask made by
+// the VOP3P clamp bit instead of v_cmp + v_cndmask (see jbf_fast.hip for the unit / pair geometry):
+//   * same-label test: labels are staged as floats (superpixel indices, |l| < 2^24; 1e9 for an invalid tap), and
+//     m = clamp(1 - (l - l_centre)^2);
+//   * invalid taps enter the pass-3 sums with v = clamp(2 d) = 0;
+//   * colour rule: m = clamp(thr - cd) with the integer threshold of the tap's rank, arg = fma(-cd, scale*m, ls);
+//   * depth rule: m = clamp((T2 - t^2) * 2^100), arg -= (t*m)*t;
+//   * the rank of a tap (number of valid taps up to it, scan order) is a running LDS byte address: validity
+//     sits in the spare byte of the packed BGRX word as 0 / 8 and is added by one v_add_u32_sdwa per tap; the
+//     (scale, threshold) pair of that rank is one ds_read_b64.
+// Scales are kept finite (<= 3e38) so that 0 * scale is 0; the reference's 0/0 = NaN case (Q6: flat patch, so
+// adaptive sigma == 0, and a rank whose table sigma has underflowed) is re-created by a rare post-pass.
+// -------------------------------------------------------------------------------------------------
+typedef float e_f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t e_u2 __attribute__((ext_vector_type(2)));
+
+constexpr int kE7BX = 32, kE7BY = 8;        // threads; tile = 64 x 8 pixels
+
+struct Enh7PkDev {
+    const float* rd;
+    const uint8_t* bgr;
+    const int32_t* labels;
+    float* out;
+    int width, height;
+    float kc1, sd, t2_skip, exp_zero;
+    int kinf;                                   // first rank whose table scale is +inf in the reference's arithmetic
+    __attribute__((aligned(8))) float lsp[98];  // [(row*7 + unit)*2 + pixel of the pair]: log2 of the spatial table
+    float tinv[50];                             // finite
+    float tthr[50];
+};
+
+__device__ __forceinline__ e_f2 e_fma(e_f2 a, e_f2 b, e_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ e_f2 e_bcast(float v) { return e_f2{v, v}; }
+__device__ __forceinline__ e_f2 e_add_clamp(e_f2 a, e_f2 b)
+{
+    e_f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ e_f2 e_mul_clamp(e_f2 a, e_f2 b)
+{
+    e_f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// clamp(c - a*b)
+__device__ __forceinline__ e_f2 e_fnma_clamp(e_f2 a, e_f2 b, e_f2 c)
+{
+    e_f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// v_min_f32 without the canonicalising v_max that fminf() puts in front of it (operands are never signalling NaNs)
+__device__ __forceinline__ float min_raw(float x, float y)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+// acc + byte 3 of w
+__device__ __forceinline__ uint32_t add_byte3(uint32_t w, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD"
+        : "=v"(r) : "v"(w), "v"(acc));
+    return r;
+}
+
+__global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkDev a)
+{
+    constexpr int WIN = 7, R = 3, HALF = 3, SEGP = 4;
+    constexpr int NT = kE7BX * kE7BY;
+    constexpr int TW = kE7BX * 2, TH = kE7BY;
+    constexpr int P = TW + 2 * R, LH = TH + 2 * R;          // P is even: a thread's window starts on an even column
+    __shared__ __attribute__((aligned(16))) float s_d[LH * P];
+    __shared__ __attribute__((aligned(16))) uint32_t s_c[LH * P];   // BGR in bytes 0..2, validity (0 / 8) in byte 3
+    __shared__ __attribute__((aligned(16))) uint32_t s_n[LH * P];
+    __shared__ __attribute__((aligned(16))) float s_l[LH * P];
+    __shared__ __attribute__((aligned(8))) float2 s_t[50];
+
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < P * LH; i += NT) {
+        const int ly = i / P, lx = i - ly * P;
+        const int gx = x0 + lx - R, gy = y0 + ly - R;
+        float d = 0.0f;
+        uint32_t c = 0;
+        int32_t l = 0;
+        if (gx >= 0 && gx < a.width && gy >= 0 && gy < a.height) {
+            const size_t q = (size_t)gy * a.width + gx;
+            d = a.rd[q];
+            c = load_bgrx(a.bgr, q);
+            l = a.labels[q];
+        }
+        const bool valid = d > 50.0f;
+        s_d[i] = valid ? d : 0.0f;
+        s_c[i] = c | (valid ? 0x08000000u : 0u);
+        s_n[i] = (kMagic + kOff) - dot4u(c, c);
+        s_l[i] = valid ? (float)l : 1.0e9f;          // never within 1 of a label (|label| < 2^24, -1 = unassigned included)
+    }
+    if (tid < 50) s_t[tid] = make_float2(a.tinv[tid], a.tthr[tid]);
+    __syncthreads();
+
+    const int tx = tid % kE7BX, ty = tid / kE7BX;
+    const int xb = x0 + 2 * tx, y = y0 + ty;
+    if (xb >= a.width || y >= a.height) return;
+    const bool has1 = xb + 1 < a.width;
+    const int sx = 2 * tx;                                   // LDS column of this pair's first window column
+    const size_t p = (size_t)y * a.width + xb;
+
+    uint32_t cc[2];
+    e_f2 negC, cl;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        cc[h] = s_c[(ty + R) * P + sx + R + h] & 0x00ffffffu;
+        negC[h] = -(kBiasF + (float)dot4u(cc[h], cc[h]));
+    }
+    cl.x = (float)a.labels[p];                               // the centre's label counts even if its depth is invalid
+    cl.y = has1 ? (float)a.labels[p + 1] : 2.0e9f;
+
+    // unit u of a row: (tap of p0, tap of p1) taken from ONE aligned LDS pair -- straight / swapped / leftover
+    auto pick_u = [&](const e_u2* v, int u, uint32_t& v0, uint32_t& v1) {
+        if (u <= HALF) { v0 = v[u].x; v1 = v[u].y; }
+        else if (u < WIN - 1) { v0 = v[u - HALF].y; v1 = v[u - HALF].x; }
+        else { v0 = v[0].y; v1 = v[HALF].x; }
+    };
+    auto pick_f = [&](const e_f2* v, int u) -> e_f2 {
+        if (u <= HALF) return v[u];
+        if (u < WIN - 1) return __builtin_shufflevector(v[u - HALF], v[u - HALF], 1, 0);
+        return e_f2{v[0].y, v[HALF].x};
+    };
+    auto load_f = [&](const float* plane, int i, e_f2* out) {
+#pragma unroll
+        for (int m = 0; m < SEGP; m++) out[m] = *reinterpret_cast<const e_f2*>(&plane[(ty + i) * P + sx + 2 * m]);
+    };
+    auto load_u = [&](const uint32_t* plane, int i, e_u2* out) {
+#pragma unroll
+        for (int m = 0; m < SEGP; m++) out[m] = *reinterpret_cast<const e_u2*>(&plane[(ty + i) * P + sx + 2 * m]);
+    };
+    const e_f2 one = e_bcast(1.0f);
+    auto label_mask = [&](const e_f2* lp, int u) -> e_f2 {
+        const e_f2 dl = pick_f(lp, u) - cl;
+        return e_fnma_clamp(dl, dl, one);                    // 1 for the centre's label, 0 otherwise (and for invalid taps)
+    };
+
+    // -cd (exact) of the two taps of unit u
+    auto unit_ncd = [&](const e_u2* cp, const e_u2* np, int u) -> e_f2 {
+        uint32_t c0, c1, n0, n1;
+        pick_u(cp, u, c0, c1);
+        pick_u(np, u, n0, n1);
+        const uint32_t u0 = (dot4u(c0, cc[0]) << 1) + n0;
+        const uint32_t u1 = (dot4u(c1, cc[1]) << 1) + n1;
+        return e_f2{__uint_as_float(u0), __uint_as_float(u1)} + negC;
+    };
+
+    // ---- pass 1: label-restricted weighted average (.cu:116-139) --------------------------------------
+    // (row loops stay rolled: 100 VGPRs / 4 waves per SIMD; -cd is recomputed in pass 3 rather than cached)
+    e_f2 wsum = e_bcast(0.0f), wgt = e_bcast(0.0f);
+    e_f2 kc1 = e_bcast(a.kc1);
+    asm volatile("" : "+v"(kc1));          // VGPR pair: the only scalar operand of the argument fma is the log2(S) pair
+#pragma unroll 1
+    for (int i = 0; i < WIN; i++) {
+        e_f2 dp[SEGP], lp[SEGP];
+        e_u2 cp[SEGP], np[SEGP];
+        load_f(s_d, i, dp);
+        load_f(s_l, i, lp);
+        load_u(s_c, i, cp);
+        load_u(s_n, i, np);
+#pragma unroll
+        for (int u = 0; u < WIN; u++) {
+            const e_f2 nc = unit_ncd(cp, np, u);
+            const e_f2 lsj = *reinterpret_cast<const e_f2*>(&a.lsp[(i * WIN + u) * 2]);
+            const e_f2 a1 = e_fma(nc, kc1, lsj);
+            const e_f2 f = e_f2{__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)} * label_mask(lp, u);
+            wsum = e_fma(pick_f(dp, u), f, wsum);
+            wgt = wgt + f;
+        }
+    }
+
+    // ---- pass 2: mean absolute deviation over the same taps (.cu:143-156) ---------------------------
+    const e_f2 wavg = e_f2{wsum.x / wgt.x, wsum.y / wgt.y};    // IEEE: the integer skip thresholds below depend on it
+    e_f2 dev = e_bcast(0.0f), cnt = e_bcast(0.0f);
+#pragma unroll 1
+    for (int i = 0; i < WIN; i++) {
+        e_f2 dp[SEGP], lp[SEGP];
+        load_f(s_d, i, dp);
+        load_f(s_l, i, lp);
+#pragma unroll
+        for (int u = 0; u < WIN; u++) {
+            const e_f2 m = label_mask(lp, u);
+            const e_f2 e = pick_f(dp, u) - wavg;
+            dev.x = __builtin_fmaf(__builtin_fabsf(e.x), m.x, dev.x);
+            dev.y = __builtin_fmaf(__builtin_fabsf(e.y), m.y, dev.y);
+            cnt = cnt + m;
+        }
+    }
+
+    // ---- per pixel: adaptive sigma -> scale and integer skip threshold (.cu:171) ----------------------
+    e_f2 inv_a, nthr_a;
+    bool flat[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        float deviation = dev[h];
+        if (cnt[h] != 0.0f) deviation /= cnt[h];
+        // 5.0 is a double literal, pow(float,float) is float
+        const float asig = (float)(5.0 * (double)deviation / (double)(wavg[h] * wavg[h]));
+        const float den_a = 2 * (asig * asig);
+        flat[h] = den_a == 0.0f;
+        inv_a[h] = flat[h] ? 3.0e38f : fminf(1.4426950408889634f / den_a, 3.0e38f);
+        float thr_a;                         // smallest integer cd with fl(cd / den_a) >= x0 (exact)
+        if (flat[h]) {
+            thr_a = 1.0f;                    // cd/0 = inf for cd >= 1; 0/0 = NaN is not ">= x0" (post-pass below)
+        } else if (den_a != den_a) {
+            thr_a = 400000.0f;               // NaN sigma (non-finite depths): nothing compares ">= x0"
+        } else {
+            float c0 = ceilf(a.exp_zero * den_a);
+            c0 = fminf(fmaxf(c0, 0.0f), 400000.0f);
+            while (c0 > 0.0f && (c0 - 1.0f) / den_a >= a.exp_zero) c0 -= 1.0f;
+            while (c0 < 400000.0f && !(c0 / den_a >= a.exp_zero)) c0 += 1.0f;
+            thr_a = c0;
+        }
+        nthr_a[h] = -thr_a;
+    }
+
+    // ---- pass 3: every valid tap, colour sigma mutating with the tap's rank (.cu:158-195) ------------
+    const e_f2 T2 = e_bcast(a.t2_skip), kBig = e_bcast(0x1p100f), sd2 = e_bcast(a.sd);
+    e_f2 num = e_bcast(0.0f), den = e_bcast(0.0f);
+    uint32_t rank0 = 0, rank1 = 0;           // byte offsets into s_t (8 bytes per rank)
+    const char* tbase = reinterpret_cast<const char*>(s_t);
+#pragma unroll 1
+    for (int i = 0; i < WIN; i++) {
+        e_f2 dp[SEGP], vp[SEGP];
+        e_u2 cp[SEGP], np[SEGP];
+        load_f(s_d, i, dp);
+        load_u(s_c, i, cp);
+        load_u(s_n, i, np);
+#pragma unroll
+        for (int m = 0; m < SEGP; m++) vp[m] = e_add_clamp(dp[m], dp[m]);
+        // scan-order ranks of the row's taps: p0 covers columns 0..6 of the segment, p1 columns 1..7
+        uint32_t r0[WIN], r1[WIN];
+#pragma unroll
+        for (int j = 0; j < WIN; j++) {
+            const uint32_t w0 = (j & 1) ? cp[j >> 1].y : cp[j >> 1].x;
+            const uint32_t w1 = ((j + 1) & 1) ? cp[(j + 1) >> 1].y : cp[(j + 1) >> 1].x;
+            rank0 = add_byte3(w0, rank0);
+            rank1 = add_byte3(w1, rank1);
+            r0[j] = rank0;
+            r1[j] = rank1;
+        }
+#pragma unroll
+        for (int u = 0; u < WIN; u++) {
+            const int j0 = u <= HALF ? 2 * u : (u < WIN - 1 ? 2 * (u - HALF) + 1 : 1);
+            const int j1 = u <= HALF ? 2 * u : (u < WIN - 1 ? 2 * (u - HALF) - 1 : WIN - 2);
+            const float2 t0 = *reinterpret_cast<const float2*>(tbase + r0[j0]);
+            const float2 t1 = *reinterpret_cast<const float2*>(tbase + r1[j1]);
+            const e_f2 invl = e_f2{min_raw(inv_a.x, t0.x), min_raw(inv_a.y, t1.x)};
+            const e_f2 thr = e_f2{min_raw(nthr_a.x, t0.y), min_raw(nthr_a.y, t1.y)};
+            const e_f2 nc = unit_ncd(cp, np, u);
+            const e_f2 lsj = *reinterpret_cast<const e_f2*>(&a.lsp[(i * WIN + u) * 2]);
+            const e_f2 mc = e_add_clamp(nc, -thr);                       // 0 <=> -cd <= thr: underflowed colour factor skipped
+            const e_f2 ac = e_fma(nc, mc * invl, lsj);                    // log2(S) - cd * log2(e)/(2 cs_k^2)
+            const e_f2 dq = pick_f(dp, u);
+            const e_f2 t = (dq - wavg) * sd2;
+            const e_f2 md = e_mul_clamp(e_fma(-t, t, T2), kBig);          // 0 <=> underflowed depth factor skipped
+            const e_f2 a2 = e_fma(-(t * md), t, ac);
+            const e_f2 f = e_f2{__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+            num = e_fma(dq, f, num);
+            den = e_fma(pick_f(vp, u), f, den);
+        }
+    }
+
+    float res[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        res[h] = 0.0f;
+        if (wgt[h] > 0.0f) res[h] = (den[h] == 0.0f) ? 0.0f : num[h] / den[h];
+    }
+    // Q6 post-pass (rare): flat patch and a valid tap of the centre's exact colour whose rank has a zero table
+    // denominator -> the reference evaluates 0/0 = NaN and the NaN reaches the result
+    if ((flat[0] && wgt.x > 0.0f) || (flat[1] && wgt.y > 0.0f)) {
+        int k0 = 0, k1 = 0;
+        bool nan0 = false, nan1 = false;
+#pragma unroll 1
+        for (int i = 0; i < WIN; i++)
+#pragma unroll 1
+            for (int j = 0; j < WIN; j++) {
+                const int li = (ty + i) * P + sx + j;
+                const bool v0 = s_d[li] > 0.0f, v1 = s_d[li + 1] > 0.0f;
+                k0 += v0 ? 1 : 0;
+                k1 += v1 ? 1 : 0;
+                nan0 |= v0 && k0 >= a.kinf && (s_c[li] & 0x00ffffffu) == cc[0];        // cd == 0
+                nan1 |= v1 && k1 >= a.kinf && (s_c[li + 1] & 0x00ffffffu) == cc[1];
+            }
+        if (flat[0] && wgt.x > 0.0f && nan0) res[0] = __builtin_nanf("");
+        if (flat[1] && wgt.y > 0.0f && nan1) res[1] = __builtin_nanf("");
+    }
+    a.out[p] = res[0];
+    if (has1) a.out[p + 1] = res[1];
+}
+
 }  // namespace
 
 int launch_ers_edge_phase(int width, int height, int dir, int window, const int32_t* color_labels, const int32_t* l0,
                           const float* d0, int32_t* l1, float* d1, hipStream_t s)
 {
+    const int H = window / 2 + 3;
+    const size_t lds0 = (size_t)(64 + 2 * H) * 4 * 12, lds1 = (size_t)(kEdgeScan1 + 2 * H) * 64 * 12;
+    if (window >= 0 && (dir == 0 ? lds0 : lds1) <= 64 * 1024) {
+        if (dir == 0)
+            hipLaunchKernelGGL(edge_phase_lds_kernel<0>, dim3(ceil_div(width, 64), ceil_div(height, 4)), dim3(256), lds0, s,
+                               width, height, window, color_labels, l0, d0, l1, d1);
+        else
+            hipLaunchKernelGGL(edge_phase_lds_kernel<1>, dim3(ceil_div(width, 64), ceil_div(height, kEdgeScan1)), dim3(256),
+                               lds1, s, width, height, window, color_labels, l0, d0, l1, d1);
+        KDE_HIP_TRY(hipGetLastError());
+        return KDE_OK;
+    }
+    // very wide search windows: the rule on global memory
     dim3 grid(ceil_div(width, 64), ceil_div(height, 4));
     if (dir == 0)
         hipLaunchKernelGGL(edge_phase_kernel<0>, grid, dim3(256), 0, s, width, height, window, color_labels, l0, d0, l1, d1);
@@ -392,12 +824,74 @@ int launch_ers_edge_phase(int width, int height, int dir, int window, const int3
 
 int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr, const int32_t* labels,
                        const float* s_eff, const float* table_host, int window, float color_sigma, float depth_sigma,
-                       float exp_zero, float* out, hipStream_t s)
+                       float exp_zero, float* out, int variant, hipStream_t s)
 {
     const float cden = 2 * (color_sigma * color_sigma);
-    // tuned kernel: 7x7 window, both sigmas on, pass-1 colour factor can never underflow
+    // tuned kernels: 7x7 window, both sigmas on, pass-1 colour factor can never underflow
     const bool tuned = window == 7 && color_sigma != 0.0f && depth_sigma != 0.0f && !(195075.0f / cden >= exp_zero);
-    if (tuned) {
+    // variant 0 = built-in choice, 1 = packed-pair kernel, 2 = scalar tuned kernel, 3 = generic kernel
+    // (the packed kernel compares labels as floats: superpixel indices of a frame of <= 2^24 pixels are exact)
+    const bool can_pk = tuned && (long long)width * height <= (1LL << 24);
+    if (variant == 1 && !can_pk) return fail(KDE_ERR_INVALID, "ers: the packed kernel does not serve this configuration");
+    if (variant == 2 && !tuned) return fail(KDE_ERR_INVALID, "ers: the tuned kernel does not serve this configuration");
+    if ((variant == 0 && can_pk) || variant == 1) {
+        Enh7PkDev d;
+        memset(&d, 0, sizeof(d));
+        d.rd = rd; d.bgr = bgr; d.labels = labels; d.out = out; d.width = width; d.height = height;
+        const double log2e = 1.4426950408889634;
+        d.kc1 = (float)(log2e / (double)cden);
+        const float dden = 2.0f * (depth_sigma * depth_sigma);
+        d.sd = (float)std::sqrt(log2e / (double)dden);
+        {   // smallest q with fl(q / dden) >= x0, as a bound on ((d_q - avg) * sd)^2
+            uint32_t lo = 0, hi = 0x7f800000u;
+            auto val = [](uint32_t b) { float f; memcpy(&f, &b, 4); return f; };
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                if (val(mid) / dden >= exp_zero) hi = mid; else lo = mid + 1;
+            }
+            const double t2 = (double)val(lo) * (log2e / (double)dden);
+            d.t2_skip = t2 < 3.0e38 ? (float)t2 : 3.0e38f;
+        }
+        d.exp_zero = exp_zero;
+        auto lg = [&](int i, int j) {   // S == 0 -> factor skipped -> log2 = 0
+            const float sv = table_host[i * 7 + j];
+            return sv == 0.0f ? 0.0f : (float)std::log2((double)sv);
+        };
+        for (int i = 0; i < 7; i++)
+            for (int u = 0; u < 7; u++) {   // unit -> (tap of p0, tap of p1): see enhance7_pk_kernel
+                const int j0 = u <= 3 ? 2 * u : (u < 6 ? 2 * (u - 3) + 1 : 1);
+                const int j1 = u <= 3 ? 2 * u : (u < 6 ? 2 * (u - 3) - 1 : 5);
+                d.lsp[(i * 7 + u) * 2] = lg(i, j0);
+                d.lsp[(i * 7 + u) * 2 + 1] = lg(i, j1);
+            }
+        // rank table: c_0 = ColorSigma, c_k = c_{k-1} * 0.3f (EdgeRefinedSuperpixel.cu:172-175 while a <= 0.3 c)
+        float c = color_sigma;
+        d.tinv[0] = 1.0f;    // rank 0 = only invalid taps so far (their weight is multiplied by 0 anyway)
+        d.tthr[0] = 0.0f;
+        d.kinf = 50;
+        for (int k = 1; k < 50; k++) {
+            c *= 0.3f;
+            const float den = 2 * (c * c);
+            if (den == 0.0f) {
+                if (d.kinf == 50) d.kinf = k;
+                d.tinv[k] = 3.0e38f;
+                d.tthr[k] = -1.0f;
+            } else {
+                d.tinv[k] = (float)std::fmin(log2e / (double)den, 3.0e38);
+                int lo = 0, hi = 400000;
+                while (lo < hi) {
+                    const int mid = (lo + hi) / 2;
+                    if ((float)mid / den >= exp_zero) hi = mid; else lo = mid + 1;
+                }
+                d.tthr[k] = -(float)lo;
+            }
+        }
+        hipLaunchKernelGGL(enhance7_pk_kernel, dim3(ceil_div(width, kE7BX * 2), ceil_div(height, kE7BY)),
+                           dim3(kE7BX * kE7BY), 0, s, d);
+        KDE_HIP_TRY(hipGetLastError());
+        return KDE_OK;
+    }
+    if (tuned && variant != 3) {
         Enh7Dev d;
         memset(&d, 0, sizeof(d));
         d.rd = rd; d.bgr = bgr; d.labels = labels; d.out = out; d.width = width; d.height = height;

@@ -681,6 +681,7 @@ struct kde_ers {
     PinnedBuf<float> depth_host;
     float exp_zero = 0;
     float table_host[49];                 // SpatialFilter_Host as calcSpatialFilter computed it
+    int enhance_variant = 0;              // kde_ers_set_variant
 };
 
 extern "C" int kde_ers_create(kde_ers** out, int width, int height)
@@ -730,7 +731,15 @@ extern "C" int kde_ers_edge_refining(kde_ers* h, const int32_t* color_labels_dev
     // depthmap_enhancement (.cu:220-221)
     KDE_TRY(launch_ers_enhance(W, H, h->depth_a.p, bgr_dev, h->labels_a.p, h->s_eff.p, h->table_host,
                                kde_ers::WindowSize, kde_ers::ColorSigma, kde_ers::DepthSigma, h->exp_zero,
-                               h->refined_depth.p, s));
+                               h->refined_depth.p, h->enhance_variant, s));
+    return KDE_OK;
+}
+
+extern "C" int kde_ers_set_variant(kde_ers* h, int variant)
+{
+    KDE_REQUIRE(h, "kde_ers_set_variant: null handle");
+    KDE_REQUIRE(variant >= 0 && variant <= 3, "kde_ers_set_variant: variant %d out of range (0..3)", variant);
+    h->enhance_variant = variant;
     return KDE_OK;
 }
 

@@ -186,7 +186,7 @@ int launch_ers_edge_phase(int width, int height, int dir, int window, const int3
                           const float* d0, int32_t* l1, float* d1, hipStream_t s);
 int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr, const int32_t* labels,
                        const float* s_eff, const float* table_host, int window, float color_sigma, float depth_sigma,
-                       float exp_zero, float* out, hipStream_t s);
+                       float exp_zero, float* out, int variant, hipStream_t s);
 
 int launch_spdsr_init_normalized(const Camera& c, float* nxy, hipStream_t s);
 int launch_spdsr_cluster_planes(int width, int height, int nclusters, const int32_t* labels, const kde_float3* pts,

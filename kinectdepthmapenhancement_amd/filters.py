@@ -333,6 +333,10 @@ class EdgeRefinedSuperpixel(_Handle):
         check(lib().kde_ers_edge_refining(self._h, color_label_device.data_ptr(), depth_label_device.data_ptr(),
                                           depth_device.data_ptr(), color_image.data_ptr(), _stream()))
 
+    def set_variant(self, v: int) -> None:
+        """0 = built-in choice, 1 = packed-pair, 2 = scalar tuned, 3 = generic depthmap_enhancement kernel"""
+        check(lib().kde_ers_set_variant(self._h, int(v)))
+
     def _get(self, fn, dtype):
         p = C.c_void_p()
         check(getattr(lib(), fn)(self._h, C.byref(p)))

@@ -111,6 +111,45 @@ def test_k10_flat_patch_nan_quirk(torch_cuda, F, oracle):
     assert_depth_close(got, ref, 1e-4, what="K10 NaN quirk")
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_k10_every_kernel_variant(torch_cuda, F, oracle, synth, frame, variant):
+    """packed-pair / scalar tuned / generic depthmap_enhancement kernels against the oracle: natural-looking
+    frame with holes, the crafted speckle case, the flat-patch NaN quirk and a ragged size."""
+    cases = []
+    bgr, depth, K, pts = _inputs(oracle, synth, frame, 31, 203, 77)
+    sp = oracle.dasp_segmentation(bgr, pts, 5, 7, K, 200.0, 40.0, 0.0, 1)[0]
+    da = oracle.dasp_segmentation(bgr, pts, 5, 7, K, 100.0, 20.0, 200.0, 1)[0]
+    cases.append(("synth", sp, da, depth, bgr))
+    rng = np.random.default_rng(17)
+    H, W = 51, 97                                                  # odd width: the last pixel pair is half outside
+    cl = (np.arange(W)[None, :] // 7 + 13 * (np.arange(H)[:, None] // 5)).astype(np.int32)
+    dl = ((np.arange(W)[None, :] + 2) // 7 + 13 * ((np.arange(H)[:, None] + 3) // 5)).astype(np.int32)
+    d2 = (800 + 40 * dl + rng.normal(0, 30, (H, W))).astype(np.float32)
+    d2[rng.random((H, W)) < 0.25] = 0                              # many invalid taps: ranks differ from tap indices
+    b2 = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    b2[:, 40:60] = 77                                              # a flat-colour band (cd == 0 taps)
+    cases.append(("crafted", cl, dl, d2, b2))
+    flat_d = np.full((24, 40), 1024.0, np.float32)
+    flat_d[5:9, 7:30] = 0
+    cases.append(("flat", np.zeros((24, 40), np.int32), np.zeros((24, 40), np.int32), flat_d, np.full((24, 40, 3), 9, np.uint8)))
+    for name, cl_, dl_, d_, b_ in cases:
+        h, w = d_.shape
+        ers = F.EdgeRefinedSuperpixel(w, h)
+        ers.set_variant(variant)
+        ers.EdgeRefining(dev(torch_cuda, cl_), dev(torch_cuda, dl_), dev(torch_cuda, d_), dev(torch_cuda, b_))
+        rl, rd9 = oracle.ers_edge_refining(cl_, dl_, d_)
+        assert np.array_equal(host(ers.getRefinedLabels_Device()), rl)
+        assert np.array_equal(host(ers.getEdgeStageDepth_Device()), rd9)
+        with oracle.ers_flags((h, w)) as ill:
+            ref = oracle.ers_enhance(rd9, b_, rl)
+        if name == "flat":
+            assert np.isnan(ref).sum() > 0
+        assert_depth_close(host(ers.getRefinedDepth_Device()), ref, 1e-4, ill=ill, what=f"K10 variant {variant} {name}")
+    from kinectdepthmapenhancement_amd import KdeError
+    with pytest.raises(KdeError):
+        F.EdgeRefinedSuperpixel(32, 32).set_variant(9)
+
+
 def test_rgbf_pipeline_on_reference_color_fixture(torch_cuda, F, oracle, color_fixture, synth):
     _, depth = synth.make_frame(1, 640, 480)
     K = synth.intrinsics(640, 480)
