@@ -15,17 +15,7 @@
 namespace kde {
 namespace {
 
-// ---- K5 init_LD (.cu:3-14) ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void init_ld_kernel(DaspGeom g, kde_label_distance* __restrict__ ld)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= g.width || y >= g.height) return;
-    kde_label_distance v;
-    v.l = (y / g.wy) * g.cols + (x / g.wx);
-    v.d = 999999.9f;
-    ld[(size_t)y * g.width + x] = v;
-}
+// ---- K5 init_LD (.cu:3-14): folded into the first calculateLD (calc_ld_kernel<.., FIRST>) --------------
 
 // ---- K6 sampleInitialClusters<16> (.cu:16-165) ---------------------------------------------------
 // one 64-lane wavefront = 4 clusters x 16 candidates
@@ -118,16 +108,22 @@ struct CalcSets {
     CalcSet s[NS];
 };
 
-template <int NS, bool USE_LDS>
+// FIRST = the assignment step that follows sampleInitialClusters: init_LD (K5) is folded in -- the previous
+// assignment is "own grid cell at distance 999999.9" and is formed in registers instead of being written by one
+// kernel and read back by the next -- and all NS segmenters still share the sampled clusters, so the colour /
+// spatial / depth distances of the 16 candidates are computed ONCE and only the weighted sum and the argmin run
+// per segmenter (set 0's cluster table serves all).
+template <int NS, bool USE_LDS, bool FIRST>
 __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
                                                      const kde_float3* __restrict__ pts, CalcSets<NS> sets, float win2)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ClusterRec* recs = reinterpret_cast<ClusterRec*>(smem);
     const int nclusters = g.rows * g.cols;
+    constexpr int NTAB = FIRST ? 1 : NS;
     if (USE_LDS) {
 #pragma unroll
-        for (int n = 0; n < NS; n++)
+        for (int n = 0; n < NTAB; n++)
             for (int i = threadIdx.x; i < nclusters; i += 256) {
                 const kde_superpixel m = sets.s[n].mean[i];
                 ClusterRec r;
@@ -149,41 +145,27 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
     const float c0 = (float)bgr[p * 3], c1 = (float)bgr[p * 3 + 1], c2 = (float)bgr[p * 3 + 2];
     const float z = pts[p].z;
 
-#pragma unroll
-    for (int n = 0; n < NS; n++) {
-        const CalcSet& cs = sets.s[n];
-        const kde_label_distance cur = cs.ld[p];
-        const int ccx = cur.l % g.cols, ccy = cur.l / g.cols;
-        float dist[16];
-        int lab[16];
-#pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int rx = ccx - 2 + (t & 3), ry = ccy - 2 + (t >> 2);
-            if (rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows) {
-                const int id = ry * g.cols + rx;
-                float mr, mg, mb, cz;
-                int mx, my;
-                if (USE_LDS) {
-                    const ClusterRec r = recs[n * nclusters + id];
-                    mr = r.r; mg = r.g; mb = r.b; mx = r.x; my = r.y; cz = r.cz;
-                } else {
-                    const kde_superpixel m = cs.mean[id];
-                    mr = (float)m.r; mg = (float)m.g; mb = (float)m.b; mx = m.x; my = m.y;
-                    cz = cs.centers[id].z;
-                }
-                const float e0 = c0 - mr, e1 = c1 - mg, e2 = c2 - mb;
-                const float color_distance = e0 * e0 + e1 * e1 + e2 * e2;
-                const float px = (float)(x - mx), py = (float)(y - my);
-                const float spatial_distance = sqrtf(px * px + py * py) * win2;
-                float depth_distance = 0.0f;
-                if (z > 50.0f && cz > 50.0f) depth_distance = fabsf(z - cz);
-                dist[t] = color_distance * cs.kc + spatial_distance * cs.ks + depth_distance * cs.kd;   // .cu:218
-                lab[t] = id;
-            } else {
-                dist[t] = cur.d;   // .cu:221-224
-                lab[t] = cur.l;
-            }
+    // the three distances of candidate t against cluster table n (.cu:196-217)
+    auto candidate = [&](int n, int id, float& color_distance, float& spatial_distance, float& depth_distance) {
+        float mr, mg, mb, cz;
+        int mx, my;
+        if (USE_LDS) {
+            const ClusterRec r = recs[n * nclusters + id];
+            mr = r.r; mg = r.g; mb = r.b; mx = r.x; my = r.y; cz = r.cz;
+        } else {
+            const kde_superpixel m = sets.s[n].mean[id];
+            mr = (float)m.r; mg = (float)m.g; mb = (float)m.b; mx = m.x; my = m.y;
+            cz = sets.s[n].centers[id].z;
         }
+        const float e0 = c0 - mr, e1 = c1 - mg, e2 = c2 - mb;
+        color_distance = e0 * e0 + e1 * e1 + e2 * e2;
+        const float px = (float)(x - mx), py = (float)(y - my);
+        spatial_distance = sqrtf(px * px + py * py) * win2;
+        depth_distance = 0.0f;
+        if (z > 50.0f && cz > 50.0f) depth_distance = fabsf(z - cz);
+    };
+    // 16-way tree argmin with the reference's strict '>' (.cu:226-305), then the invalid-depth rule (.cu:308-312)
+    auto reduce_store = [&](const CalcSet& cs, float* dist, int* lab) {
 #pragma unroll
         for (int step = 8; step >= 1; step >>= 1) {
 #pragma unroll
@@ -197,12 +179,98 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
         kde_label_distance o;
         o.l = lab[0];
         o.d = dist[0];
-        if (z < 50.0f && cs.depth_on) {   // .cu:308-312
+        if (z < 50.0f && cs.depth_on) {
             o.l = -1;
             o.d = 0.0f;
         }
         cs.ld[p] = o;
         cs.labels[p] = o.l;
+    };
+
+    if (FIRST) {
+        kde_label_distance cur;                                   // init_LD (.cu:3-14)
+        cur.l = (y / g.wy) * g.cols + (x / g.wx);
+        cur.d = 999999.9f;
+        const int ccx = cur.l % g.cols, ccy = cur.l / g.cols;
+        // candidates t and t + 8 are generated together and meet in the first level of the tree at once, so only
+        // 8 (distance, label) entries per segmenter stay live
+        float dist[NS][8];
+        int lab[NS][8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            float cd[2], sd[2], dd[2];
+            int id[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int tt = t + 8 * h;
+                const int rx = ccx - 2 + (tt & 3), ry = ccy - 2 + (tt >> 2);
+                id[h] = -1;
+                cd[h] = sd[h] = dd[h] = 0.0f;
+                if (rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows) {
+                    id[h] = ry * g.cols + rx;
+                    candidate(0, id[h], cd[h], sd[h], dd[h]);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NS; n++) {
+                const CalcSet& cs = sets.s[n];
+                // .cu:218 for a cluster inside the grid, :221-224 (previous assignment) otherwise
+                const float d_lo = id[0] >= 0 ? cd[0] * cs.kc + sd[0] * cs.ks + dd[0] * cs.kd : cur.d;
+                const float d_hi = id[1] >= 0 ? cd[1] * cs.kc + sd[1] * cs.ks + dd[1] * cs.kd : cur.d;
+                const int l_lo = id[0] >= 0 ? id[0] : cur.l, l_hi = id[1] >= 0 ? id[1] : cur.l;
+                const bool take = d_lo > d_hi;             // tree level "step 8", strict '>'
+                dist[n][t] = take ? d_hi : d_lo;
+                lab[n][t] = take ? l_hi : l_lo;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            const CalcSet& cs = sets.s[n];
+#pragma unroll
+            for (int step = 4; step >= 1; step >>= 1) {
+#pragma unroll
+                for (int t = 0; t < step; t++) {
+                    if (dist[n][t] > dist[n][t + step]) {
+                        lab[n][t] = lab[n][t + step];
+                        dist[n][t] = dist[n][t + step];
+                    }
+                }
+            }
+            kde_label_distance o;
+            o.l = lab[n][0];
+            o.d = dist[n][0];
+            if (z < 50.0f && cs.depth_on) {   // .cu:308-312
+                o.l = -1;
+                o.d = 0.0f;
+            }
+            cs.ld[p] = o;
+            cs.labels[p] = o.l;
+        }
+        return;
+    }
+
+#pragma unroll
+    for (int n = 0; n < NS; n++) {
+        const CalcSet& cs = sets.s[n];
+        const kde_label_distance cur = cs.ld[p];
+        const int ccx = cur.l % g.cols, ccy = cur.l / g.cols;
+        float dist[16];
+        int lab[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int rx = ccx - 2 + (t & 3), ry = ccy - 2 + (t >> 2);
+            if (rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows) {
+                const int id = ry * g.cols + rx;
+                float color_distance, spatial_distance, depth_distance;
+                candidate(n, id, color_distance, spatial_distance, depth_distance);
+                dist[t] = color_distance * cs.kc + spatial_distance * cs.ks + depth_distance * cs.kd;   // .cu:218
+                lab[t] = id;
+            } else {
+                dist[t] = cur.d;   // .cu:221-224
+                lab[t] = cur.l;
+            }
+        }
+        reduce_store(cs, dist, lab);
     }
 }
 
@@ -316,13 +384,6 @@ __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const
 
 }  // namespace
 
-int launch_dasp_init_ld(const DaspGeom& g, kde_label_distance* ld, hipStream_t s)
-{
-    hipLaunchKernelGGL(init_ld_kernel, dim3(ceil_div(g.width, 64), ceil_div(g.height, 4)), dim3(256), 0, s, g, ld);
-    KDE_HIP_TRY(hipGetLastError());
-    return KDE_OK;
-}
-
 int launch_dasp_sample(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
                        kde_float3* centers, hipStream_t s)
 {
@@ -345,43 +406,48 @@ static CalcSet make_set(const DaspGeom& g, kde_label_distance* ld, const kde_sup
     return c;
 }
 
-int launch_dasp_calc_ld(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld,
-                        const kde_superpixel* mean, const kde_float3* centers, int32_t* labels, float color_sigma,
-                        float spatial_sigma, float depth_sigma, hipStream_t s)
+template <int NS>
+static int launch_calc_sets(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const CalcSets<NS>& sets, bool first,
+                            hipStream_t s)
 {
     const float half = (float)(g.wx + g.wy) / 2.0f;
     const float win2 = half * half;
-    CalcSets<1> sets;
-    sets.s[0] = make_set(g, ld, mean, centers, labels, color_sigma, spatial_sigma, depth_sigma);
     const int nclusters = g.rows * g.cols;
+    const int tables = first ? 1 : NS;
+    const bool lds = tables * nclusters <= kMaxLdsClusters;
+    const size_t bytes = lds ? (size_t)tables * nclusters * sizeof(ClusterRec) : 0;
     dim3 grid(ceil_div(g.width, 64), ceil_div(g.height, 4));
-    if (nclusters <= kMaxLdsClusters)
-        hipLaunchKernelGGL((calc_ld_kernel<1, true>), grid, dim3(256), (size_t)nclusters * sizeof(ClusterRec), s, g, bgr, pts, sets, win2);
-    else
-        hipLaunchKernelGGL((calc_ld_kernel<1, false>), grid, dim3(256), 0, s, g, bgr, pts, sets, win2);
+    if (first) {
+        if (lds) hipLaunchKernelGGL((calc_ld_kernel<NS, true, true>), grid, dim3(256), bytes, s, g, bgr, pts, sets, win2);
+        else hipLaunchKernelGGL((calc_ld_kernel<NS, false, true>), grid, dim3(256), 0, s, g, bgr, pts, sets, win2);
+    } else {
+        if (lds) hipLaunchKernelGGL((calc_ld_kernel<NS, true, false>), grid, dim3(256), bytes, s, g, bgr, pts, sets, win2);
+        else hipLaunchKernelGGL((calc_ld_kernel<NS, false, false>), grid, dim3(256), 0, s, g, bgr, pts, sets, win2);
+    }
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }
 
-// both segmenters of a pipeline in one pass (see CalcSet)
+// first = the step right after sampleInitialClusters (init_LD is folded in, see calc_ld_kernel)
+int launch_dasp_calc_ld(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld,
+                        const kde_superpixel* mean, const kde_float3* centers, int32_t* labels, float color_sigma,
+                        float spatial_sigma, float depth_sigma, bool first, hipStream_t s)
+{
+    CalcSets<1> sets;
+    sets.s[0] = make_set(g, ld, mean, centers, labels, color_sigma, spatial_sigma, depth_sigma);
+    return launch_calc_sets<1>(g, bgr, pts, sets, first, s);
+}
+
+// both segmenters of a pipeline in one pass (see CalcSet); with first = true both read set A's sampled clusters
 int launch_dasp_calc_ld_dual(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld_a,
                              const kde_superpixel* mean_a, const kde_float3* centers_a, int32_t* labels_a,
                              const float sig_a[3], kde_label_distance* ld_b, const kde_superpixel* mean_b,
-                             const kde_float3* centers_b, int32_t* labels_b, const float sig_b[3], hipStream_t s)
+                             const kde_float3* centers_b, int32_t* labels_b, const float sig_b[3], bool first, hipStream_t s)
 {
-    const float half = (float)(g.wx + g.wy) / 2.0f;
-    const float win2 = half * half;
     CalcSets<2> sets;
     sets.s[0] = make_set(g, ld_a, mean_a, centers_a, labels_a, sig_a[0], sig_a[1], sig_a[2]);
     sets.s[1] = make_set(g, ld_b, mean_b, centers_b, labels_b, sig_b[0], sig_b[1], sig_b[2]);
-    const int nclusters = g.rows * g.cols;
-    dim3 grid(ceil_div(g.width, 64), ceil_div(g.height, 4));
-    if (2 * nclusters <= kMaxLdsClusters)
-        hipLaunchKernelGGL((calc_ld_kernel<2, true>), grid, dim3(256), (size_t)2 * nclusters * sizeof(ClusterRec), s, g, bgr, pts, sets, win2);
-    else
-        hipLaunchKernelGGL((calc_ld_kernel<2, false>), grid, dim3(256), 0, s, g, bgr, pts, sets, win2);
-    KDE_HIP_TRY(hipGetLastError());
-    return KDE_OK;
+    return launch_calc_sets<2>(g, bgr, pts, sets, first, s);
 }
 
 int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const kde_label_distance* ld,

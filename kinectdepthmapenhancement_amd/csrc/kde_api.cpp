@@ -614,11 +614,11 @@ extern "C" int kde_dasp_segmentation(kde_dasp* h, const uint8_t* bgr_dev, const 
     KDE_REQUIRE(iteration >= 0, "kde_dasp_segmentation: negative iteration count");
     hipStream_t s = as_stream(stream);
     // DepthAdaptiveSuperpixel.cu:570-586
-    KDE_TRY(launch_dasp_init_ld(h->g, h->ld.p, s));
+    // init_LD (K5) is folded into the first calculateLD: its output is only ever read there
     KDE_TRY(launch_dasp_sample(h->g, bgr_dev, points_dev, h->mean.p, h->centers.p, s));
     for (int i = 0; i < iteration; i++) {
         KDE_TRY(launch_dasp_calc_ld(h->g, bgr_dev, points_dev, h->ld.p, h->mean.p, h->centers.p, h->labels.p,
-                                    color_sigma, spatial_sigma, depth_sigma, s));
+                                    color_sigma, spatial_sigma, depth_sigma, i == 0, s));
         if (h->skip_trailing_analyze && i == iteration - 1) break;
         KDE_TRY(launch_dasp_analyze(h->g, bgr_dev, points_dev, h->ld.p, h->mean.p, h->centers.p, h->intr.p, s));
     }
@@ -822,15 +822,18 @@ struct Pipeline {
         hipStream_t s = as_stream(stream);
         const DaspGeom& g = SP->g;
         const size_t k = (size_t)g.rows * g.cols;
-        KDE_TRY(launch_dasp_init_ld(g, SP->ld.p, s));
-        KDE_TRY(launch_dasp_init_ld(g, DASP->ld.p, s));
+        // The first assignment step reads the sampled clusters once for both segmenters and forms init_LD's
+        // assignment in registers (calc_ld_kernel<.., FIRST>); DASP's own copy of the sampled clusters is only
+        // needed as the starting point of its first analyzeClusters, i.e. when there is more than one iteration.
         KDE_TRY(launch_dasp_sample(g, bgr, pts, SP->mean.p, SP->centers.p, s));
-        KDE_HIP_TRY(hipMemcpyAsync(DASP->mean.p, SP->mean.p, k * sizeof(kde_superpixel), hipMemcpyDeviceToDevice, s));
-        KDE_HIP_TRY(hipMemcpyAsync(DASP->centers.p, SP->centers.p, k * sizeof(kde_float3), hipMemcpyDeviceToDevice, s));
+        if (iters > 1) {
+            KDE_HIP_TRY(hipMemcpyAsync(DASP->mean.p, SP->mean.p, k * sizeof(kde_superpixel), hipMemcpyDeviceToDevice, s));
+            KDE_HIP_TRY(hipMemcpyAsync(DASP->centers.p, SP->centers.p, k * sizeof(kde_float3), hipMemcpyDeviceToDevice, s));
+        }
         const float sa[3] = {c1, s1, d1}, sb[3] = {c2, s2, d2};
         for (int i = 0; i < iters; i++) {
             KDE_TRY(launch_dasp_calc_ld_dual(g, bgr, pts, SP->ld.p, SP->mean.p, SP->centers.p, SP->labels.p, sa, DASP->ld.p,
-                                             DASP->mean.p, DASP->centers.p, DASP->labels.p, sb, s));
+                                             DASP->mean.p, DASP->centers.p, DASP->labels.p, sb, i == 0, s));
             if (i == iters - 1) break;   // the trailing analyzeClusters is dead for the private segmenters
             KDE_TRY(launch_dasp_analyze(g, bgr, pts, SP->ld.p, SP->mean.p, SP->centers.p, SP->intr.p, s));
             KDE_TRY(launch_dasp_analyze(g, bgr, pts, DASP->ld.p, DASP->mean.p, DASP->centers.p, DASP->intr.p, s));

@@ -169,16 +169,15 @@ int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
 struct DaspGeom {
     int width, height, rows, cols, wx, wy;
 };
-int launch_dasp_init_ld(const DaspGeom& g, kde_label_distance* ld, hipStream_t s);
 int launch_dasp_sample(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
                        kde_float3* centers, hipStream_t s);
 int launch_dasp_calc_ld(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld,
                         const kde_superpixel* mean, const kde_float3* centers, int32_t* labels, float color_sigma,
-                        float spatial_sigma, float depth_sigma, hipStream_t s);
+                        float spatial_sigma, float depth_sigma, bool first, hipStream_t s);
 int launch_dasp_calc_ld_dual(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld_a,
                              const kde_superpixel* mean_a, const kde_float3* centers_a, int32_t* labels_a,
                              const float sig_a[3], kde_label_distance* ld_b, const kde_superpixel* mean_b,
-                             const kde_float3* centers_b, int32_t* labels_b, const float sig_b[3], hipStream_t s);
+                             const kde_float3* centers_b, int32_t* labels_b, const float sig_b[3], bool first, hipStream_t s);
 int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const kde_label_distance* ld,
                         kde_superpixel* mean, kde_float3* centers, const float* intr_dev, hipStream_t s);
 
