@@ -201,7 +201,8 @@ int kde_ers_edge_refining(kde_ers* h, const int32_t* color_labels_dev, const int
                           const float* depth_dev, const uint8_t* bgr_dev, void* stream);
 /* (no reference counterpart) which depthmap_enhancement kernel serves the handle: 0 = built-in choice,
  * 1 = packed-pair kernel (labels are superpixel indices, exact as floats for frames of <= 2^24 pixels),
- * 2 = scalar tuned kernel, 3 = generic kernel.  For A/B measurements and the per-kernel parity tests. */
+ * 2 = scalar tuned kernel, 3 = generic kernels (any-window depthmap_enhancement, and edge_refining as two
+ * launches on global memory instead of the fused LDS kernel).  For A/B measurements and the per-kernel parity tests. */
 int kde_ers_set_variant(kde_ers* h, int variant);
 /* the two kernels individually, for per-kernel parity tests:
  * edge_refining (.cu:4-102; snapshot semantics) on the object-owned label/depth copies,

@@ -36,22 +36,31 @@ __global__ __launch_bounds__(64) void sample_clusters_kernel(DaspGeom g, const u
     const long npix = (long)g.width * g.height;
     const uint8_t* ca = bgr + ((size_t)around_y * g.width + around_x) * 3;
     const float a0 = (float)ca[0], a1 = (float)ca[1], a2 = (float)ca[2];
+    // The 11x11 taps are addressed ABSOLUTELY in the reference (idx = yy*width + xx, .cu:52-54), i.e. they are the
+    // same 121 colours for every candidate of every cluster: stage them once per wavefront instead of issuing
+    // 363 dependent byte loads per thread.
+    __shared__ float taps[121][3];
+    for (int i = lane; i < 121; i += 64) {
+        const int yy = i / 11 - 5, xx = i % 11 - 5;
+        const long idx = (long)yy * g.width + xx;
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+        if (idx >= 0 && idx < npix) {
+            t0 = (float)bgr[idx * 3];
+            t1 = (float)bgr[idx * 3 + 1];
+            t2 = (float)bgr[idx * 3 + 2];
+        }
+        taps[i][0] = t0;
+        taps[i][1] = t1;
+        taps[i][2] = t2;
+    }
+    __syncthreads();
     float sumG = 0.0f;
     int count = 0;
-    for (int yy = -5; yy <= 5; yy++) {
-        for (int xx = -5; xx <= 5; xx++) {
-            const long idx = (long)yy * g.width + xx;   // absolute index, .cu:52-54
-            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
-            if (idx >= 0 && idx < npix) {
-                t0 = (float)bgr[idx * 3];
-                t1 = (float)bgr[idx * 3 + 1];
-                t2 = (float)bgr[idx * 3 + 2];
-            }
-            const float d0 = a0 - t0, d1 = a1 - t1, d2 = a2 - t2;
-            const float gr = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-            count += gr > 0.0f ? 1 : 0;
-            sumG += gr;
-        }
+    for (int i = 0; i < 121; i++) {               // yy outer, xx inner: the reference's summation order
+        const float d0 = a0 - taps[i][0], d1 = a1 - taps[i][1], d2 = a2 - taps[i][2];
+        const float gr = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+        count += gr > 0.0f ? 1 : 0;
+        sumG += gr;
     }
     float gradient = sumG / (float)count;
     int ax = around_x, ay = around_y;

@@ -14,8 +14,137 @@ namespace kde {
 namespace {
 
 // -------------------------------------------------------------------------------------------------
-// K9, one phase.  AT(k) addresses coordinate k along the scan line of this thread.
+// K9 rule for ONE output position `pos` of a scan line of length `len` (.cu:4-102 in gather form):
+// L(k) / C(k) / D(k) read the phase-start depth label, colour label and depth at scan position k.
+// Reads stay inside [pos - 2 - half, pos + 2 + half] and [0, len).
 // -------------------------------------------------------------------------------------------------
+template <typename FL, typename FC, typename FD>
+__device__ __forceinline__ void edge_rule(int pos, int len, int half, FL L, FC C, FD D, int32_t& out_label,
+                                          float& out_depth)
+{
+    out_label = L(pos);
+    bool have_label = false;
+    bool zero = false;
+    for (int s = pos + 2; s >= pos - 2; s--) {
+        if (s < 0 || s + 1 >= len) continue;
+        if (L(s) == L(s + 1)) continue;
+        const int cur = C(s);
+        // search outwards, left candidate first (.cu:25-55)
+        int branch = 0, tp = 0;   // 1 = found on the left at tp, 2 = found on the right at tp
+        for (int d = 1; d <= half && branch == 0; d++) {
+            if (s - d < 0 && s + d >= len) break;
+            if (s - d >= 0 && C(s - d) != cur) {
+                branch = 1;
+                tp = s - d;
+            } else if (s + d < len && C(s + d) != cur) {
+                branch = 2;
+                tp = s + d;
+            }
+        }
+        if (branch == 1) {
+            // pixels tp+1 .. s take the label right of the source (.cu:32-38)
+            if (pos >= tp + 1 && pos <= s) {
+                if (!have_label) {
+                    out_label = L(s + 1);
+                    have_label = true;
+                }
+                const float dp = D(pos);
+                if (fabsf(dp - D(pos + 1)) > dp * 0.1f) zero = true;
+            }
+        } else if (branch == 2) {
+            // pixels s+1 .. tp-1 take the source's label; the depth test cascades (.cu:45-51)
+            if (pos >= s + 1 && pos <= tp - 1) {
+                if (!have_label) {
+                    out_label = L(s);
+                    have_label = true;
+                }
+                float prev = D(s);
+                bool z = false;
+                for (int i = s + 1; i <= pos; i++) {
+                    float c = D(i);
+                    z = fabsf(c - prev) > c * 0.1f;
+                    if (z) c = 0.0f;
+                    prev = c;
+                }
+                if (z) zero = true;
+            }
+        }
+    }
+    out_depth = zero ? 0.0f : D(pos);
+}
+
+// The same rule with every read issued up front and no divergent control flow: the 6 depth labels, 5 + 2*HALF
+// colour labels and 4 depths the rule can touch around `pos` are loaded into registers (independent loads instead
+// of a chain of ~40 dependent ones), then the five sources are evaluated with selects.  Which source may write
+// `pos`, and how far its outward search must reach to do so, is static per source:
+//   left branch  (tp = s-d): pos in [tp+1, s]   <=> s >= pos   and d >= s-pos+1
+//   right branch (tp = s+d): pos in [s+1, tp-1] <=> s <  pos   and d >= pos-s+1, cascade over D(s..pos)
+template <int HALF, typename FL, typename FC, typename FD>
+__device__ __forceinline__ void edge_rule_window(int pos, int len, FL L, FC C, FD D, int32_t& out_label, float& out_depth)
+{
+    auto clampk = [&](int k) { return k < 0 ? 0 : (k >= len ? len - 1 : k); };   // out-of-line values are never used
+    int32_t Lw[6], Cw[5 + 2 * HALF];
+    float Dw[4];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Lw[i] = L(clampk(pos - 2 + i));
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int s = pos - 2 + i;
+        any |= s >= 0 && s + 1 < len && Lw[i] != Lw[i + 1];
+    }
+    out_label = Lw[2];
+    if (!__builtin_amdgcn_ballot_w64(any)) {       // no lane of the wavefront is near a depth-label boundary
+        out_depth = D(pos);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 5 + 2 * HALF; i++) Cw[i] = C(clampk(pos - 2 - HALF + i));
+#pragma unroll
+    for (int i = 0; i < 4; i++) Dw[i] = D(clampk(pos - 2 + i));
+
+    bool have_label = false, zero = false;
+#pragma unroll
+    for (int si = 4; si >= 0; si--) {              // s = pos + 2 ... pos - 2: the last writer is met first
+        const int s = pos - 2 + si;
+        const bool boundary = s >= 0 && s + 1 < len && Lw[si] != Lw[si + 1];
+        const int32_t cur = Cw[si + HALF];
+        int branch = 0, dist = 0;
+#pragma unroll
+        for (int d = 1; d <= HALF; d++) {          // left candidate first (.cu:25-55)
+            const bool left = s - d >= 0 && Cw[si + HALF - d] != cur;
+            const bool right = s + d < len && Cw[si + HALF + d] != cur;
+            const bool open = branch == 0;
+            dist = (open && (left || right)) ? d : dist;
+            branch = open ? (left ? 1 : (right ? 2 : 0)) : branch;
+        }
+        if (si >= 2) {
+            // pixels tp+1 .. s take the label right of the source (.cu:32-38)
+            const bool hit = boundary && branch == 1 && dist >= si - 1;
+            out_label = (hit && !have_label) ? Lw[si + 1] : out_label;
+            have_label |= hit;
+            zero |= hit && fabsf(Dw[2] - Dw[3]) > Dw[2] * 0.1f;
+        } else {
+            // pixels s+1 .. tp-1 take the source's label; the depth test cascades from s to pos (.cu:45-51)
+            const bool hit = boundary && branch == 2 && dist >= 3 - si;
+            out_label = (hit && !have_label) ? Lw[si] : out_label;
+            have_label |= hit;
+            float prev = Dw[si];
+            bool z = false;
+#pragma unroll
+            for (int i = si + 1; i <= 2; i++) {
+                float c = Dw[i];
+                z = fabsf(c - prev) > c * 0.1f;
+                c = z ? 0.0f : c;
+                prev = c;
+            }
+            zero |= hit && z;
+        }
+    }
+    out_depth = zero ? 0.0f : Dw[2];
+}
+
+// K9, one phase on global memory (any window)
 template <int DIR>
 __global__ __launch_bounds__(256) void edge_phase_kernel(int width, int height, int window,
                                                         const int32_t* __restrict__ color_labels,
@@ -29,176 +158,98 @@ __global__ __launch_bounds__(256) void edge_phase_kernel(int width, int height, 
     const int pos = DIR == 0 ? x : y;
     const size_t stride = DIR == 0 ? 1 : (size_t)width;
     const size_t base = DIR == 0 ? (size_t)y * width : (size_t)x;
-#define AT(arr, k) ((arr)[base + (size_t)(k) * stride])
-    const int half = window / 2;
-
-    int out_label = AT(L0, pos);
-    bool have_label = false;
-    bool zero = false;
-    for (int s = pos + 2; s >= pos - 2; s--) {
-        if (s < 0 || s + 1 >= len) continue;
-        if (AT(L0, s) == AT(L0, s + 1)) continue;
-        const int cur = AT(color_labels, s);
-        // search outwards, left candidate first (.cu:25-55)
-        int branch = 0, tp = 0;   // 1 = found on the left at tp, 2 = found on the right at tp
-        for (int d = 1; d <= half && branch == 0; d++) {
-            if (s - d < 0 && s + d >= len) break;
-            if (s - d >= 0 && AT(color_labels, s - d) != cur) {
-                branch = 1;
-                tp = s - d;
-            } else if (s + d < len && AT(color_labels, s + d) != cur) {
-                branch = 2;
-                tp = s + d;
-            }
-        }
-        if (branch == 1) {
-            // pixels tp+1 .. s take the label right of the source (.cu:32-38)
-            if (pos >= tp + 1 && pos <= s) {
-                if (!have_label) {
-                    out_label = AT(L0, s + 1);
-                    have_label = true;
-                }
-                const float dp = AT(D0, pos);
-                if (fabsf(dp - AT(D0, pos + 1)) > dp * 0.1f) zero = true;
-            }
-        } else if (branch == 2) {
-            // pixels s+1 .. tp-1 take the source's label; the depth test cascades (.cu:45-51)
-            if (pos >= s + 1 && pos <= tp - 1) {
-                if (!have_label) {
-                    out_label = AT(L0, s);
-                    have_label = true;
-                }
-                float prev = AT(D0, s);
-                bool z = false;
-                for (int i = s + 1; i <= pos; i++) {
-                    float c = AT(D0, i);
-                    z = fabsf(c - prev) > c * 0.1f;
-                    if (z) c = 0.0f;
-                    prev = c;
-                }
-                if (z) zero = true;
-            }
-        }
-    }
-    AT(L1, pos) = out_label;
-    AT(D1, pos) = zero ? 0.0f : AT(D0, pos);
-#undef AT
+    int32_t ol;
+    float od;
+    edge_rule(pos, len, window / 2,
+              [&](int k) { return L0[base + (size_t)k * stride]; },
+              [&](int k) { return color_labels[base + (size_t)k * stride]; },
+              [&](int k) { return D0[base + (size_t)k * stride]; }, ol, od);
+    L1[base + (size_t)pos * stride] = ol;
+    D1[base + (size_t)pos * stride] = od;
 }
 
 // -------------------------------------------------------------------------------------------------
-// K9, one phase, LDS-staged.  The rule above is a chain of DEPENDENT reads along the scan line (boundary test,
-// outward search, depth cascade): from global memory that is ~40 serial L2 round trips per wave.  Here the
-// labels / colour labels / depth of the tile plus a halo of (window/2 + 3) scan positions are staged once and
-// the same rule runs on LDS.  Tile: DIR 0 = 64 scan positions x 4 lines, DIR 1 = SCAN1 scan positions x 64
-// lines (each thread owns SCAN1/4 of them); the 64-wide axis is always x, so global accesses stay coalesced.
+// K9, both phases in ONE launch.  The rule is a chain of dependent reads along the scan line, so it runs on LDS:
+// a workgroup stages depth labels / colour labels / depth of its 64 x 16 output tile plus a halo of
+// H = window/2 + 3 on every side, evaluates the horizontal phase for the tile's columns on all 16 + 2H rows
+// into LDS (the vertical phase of the tile reads exactly those), then the vertical phase from LDS to global
+// memory.  Same snapshot semantics as two launches (D2); the horizontal result never travels through HBM.
 // -------------------------------------------------------------------------------------------------
-constexpr int kEdgeScan1 = 16;
+constexpr int kEdgeTX = 64, kEdgeTY = 16;
 
-template <int DIR>
-__global__ __launch_bounds__(256) void edge_phase_lds_kernel(int width, int height, int window,
-                                                            const int32_t* __restrict__ color_labels,
-                                                            const int32_t* __restrict__ L0, const float* __restrict__ D0,
-                                                            int32_t* __restrict__ L1, float* __restrict__ D1)
+template <int HALF>
+__global__ __launch_bounds__(256) void edge_fused_kernel(int width, int height, int window,
+                                                        const int32_t* __restrict__ color_labels,
+                                                        const int32_t* __restrict__ L0, const float* __restrict__ D0,
+                                                        int32_t* __restrict__ L2, float* __restrict__ D2)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char edge_smem[];
-    constexpr int SCAN = DIR == 0 ? 64 : kEdgeScan1;
-    constexpr int LINES = DIR == 0 ? 4 : 64;
     const int half = window / 2, H = half + 3;
-    const int ext = SCAN + 2 * H;
-    int32_t* sL = reinterpret_cast<int32_t*>(edge_smem);
-    int32_t* sC = sL + ext * LINES;
-    float* sD = reinterpret_cast<float*>(sC + ext * LINES);
+    const int EW = kEdgeTX + 2 * H, EH = kEdgeTY + 2 * H;
+    int32_t* sL = reinterpret_cast<int32_t*>(edge_smem);          // [EH][EW] inputs
+    int32_t* sC = sL + EW * EH;
+    float* sD = reinterpret_cast<float*>(sC + EW * EH);
+    int32_t* sL1 = reinterpret_cast<int32_t*>(sD + EW * EH);      // [EH][64] horizontal-phase result
+    float* sD1 = reinterpret_cast<float*>(sL1 + kEdgeTX * EH);
 
     const int tid = threadIdx.x;
-    const int scan0 = DIR == 0 ? blockIdx.x * 64 : blockIdx.y * kEdgeScan1;
-    const int line0 = DIR == 0 ? blockIdx.y * 4 : blockIdx.x * 64;
-    const int len = DIR == 0 ? width : height;
-    const int nlines = DIR == 0 ? height : width;
-    // LDS layout: DIR 0 [line][k], DIR 1 [k][line] -- x is the fastest index of both the tile and the image
-    for (int i = tid; i < ext * LINES; i += 256) {
-        int k, line;
-        if (DIR == 0) {
-            line = i / ext;
-            k = i - line * ext;
-        } else {
-            k = i / LINES;
-            line = i - k * LINES;
-        }
-        const int gk = scan0 - H + k, gl = line0 + line;
-        int32_t l = 0, c = 0;
+    const int x0 = blockIdx.x * kEdgeTX, y0 = blockIdx.y * kEdgeTY;
+    for (int i = tid; i < EW * EH; i += 256) {
+        const int r = i / EW, c = i - r * EW;
+        const int gx = x0 - H + c, gy = y0 - H + r;
+        int32_t l = 0, cl = 0;
         float d = 0.0f;
-        if (gk >= 0 && gk < len && gl < nlines) {
-            const size_t q = DIR == 0 ? (size_t)gl * width + gk : (size_t)gk * width + gl;
+        if (gx >= 0 && gx < width && gy >= 0 && gy < height) {
+            const size_t q = (size_t)gy * width + gx;
             l = L0[q];
-            c = color_labels[q];
+            cl = color_labels[q];
             d = D0[q];
         }
         sL[i] = l;
-        sC[i] = c;
+        sC[i] = cl;
         sD[i] = d;
     }
     __syncthreads();
 
-    const int line = DIR == 0 ? (tid >> 6) : (tid & 63);
-    if (line0 + line >= nlines) return;
-    const int kstride = DIR == 0 ? 1 : LINES;
-    const int lbase = (DIR == 0 ? line * ext : line) + (H - scan0) * kstride;
-#define AT(arr, k) ((arr)[lbase + (k) * kstride])
-    constexpr int PER = DIR == 0 ? 1 : kEdgeScan1 / 4;
-#pragma unroll 1
-    for (int r = 0; r < PER; r++) {
-        const int pos = scan0 + (DIR == 0 ? (tid & 63) : (tid >> 6) + 4 * r);
-        if (pos >= len) continue;
-        int out_label = AT(sL, pos);
-        bool have_label = false;
-        bool zero = false;
-        for (int s = pos + 2; s >= pos - 2; s--) {
-            if (s < 0 || s + 1 >= len) continue;
-            if (AT(sL, s) == AT(sL, s + 1)) continue;
-            const int cur = AT(sC, s);
-            int branch = 0, tp = 0;
-            for (int d = 1; d <= half && branch == 0; d++) {
-                if (s - d < 0 && s + d >= len) break;
-                if (s - d >= 0 && AT(sC, s - d) != cur) {
-                    branch = 1;
-                    tp = s - d;
-                } else if (s + d < len && AT(sC, s + d) != cur) {
-                    branch = 2;
-                    tp = s + d;
-                }
-            }
-            if (branch == 1) {
-                if (pos >= tp + 1 && pos <= s) {
-                    if (!have_label) {
-                        out_label = AT(sL, s + 1);
-                        have_label = true;
-                    }
-                    const float dp = AT(sD, pos);
-                    if (fabsf(dp - AT(sD, pos + 1)) > dp * 0.1f) zero = true;
-                }
-            } else if (branch == 2) {
-                if (pos >= s + 1 && pos <= tp - 1) {
-                    if (!have_label) {
-                        out_label = AT(sL, s);
-                        have_label = true;
-                    }
-                    float prev = AT(sD, s);
-                    bool z = false;
-                    for (int i = s + 1; i <= pos; i++) {
-                        float c = AT(sD, i);
-                        z = fabsf(c - prev) > c * 0.1f;
-                        if (z) c = 0.0f;
-                        prev = c;
-                    }
-                    if (z) zero = true;
-                }
-            }
-        }
-        const size_t q = DIR == 0 ? (size_t)(line0 + line) * width + pos : (size_t)pos * width + (line0 + line);
-        L1[q] = out_label;
-        D1[q] = zero ? 0.0f : AT(sD, pos);
+    // horizontal phase: scan position = global x, line = staged row r
+    for (int i = tid; i < kEdgeTX * EH; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const int gx = x0 + c, gy = y0 - H + r;
+        if (gx >= width || gy < 0 || gy >= height) continue;
+        const int rb = r * EW + H - x0;                            // staged index of scan position k is rb + k
+        int32_t ol;
+        float od;
+        if (HALF > 0)
+            edge_rule_window<HALF>(gx, width, [&](int k) { return sL[rb + k]; }, [&](int k) { return sC[rb + k]; },
+                                   [&](int k) { return sD[rb + k]; }, ol, od);
+        else
+            edge_rule(gx, width, half, [&](int k) { return sL[rb + k]; }, [&](int k) { return sC[rb + k]; },
+                      [&](int k) { return sD[rb + k]; }, ol, od);
+        sL1[i] = ol;
+        sD1[i] = od;
     }
-#undef AT
+    __syncthreads();
+
+    // vertical phase on the horizontal result: scan position = global y, line = column c
+    for (int i = tid; i < kEdgeTX * kEdgeTY; i += 256) {
+        const int ry = i >> 6, c = i & 63;
+        const int gx = x0 + c, gy = y0 + ry;
+        if (gx >= width || gy >= height) continue;
+        const int rr = H - y0;                                     // staged row of scan position k is rr + k
+        int32_t ol;
+        float od;
+        if (HALF > 0)
+            edge_rule_window<HALF>(gy, height, [&](int k) { return sL1[(rr + k) * kEdgeTX + c]; },
+                                   [&](int k) { return sC[(rr + k) * EW + c + H]; },
+                                   [&](int k) { return sD1[(rr + k) * kEdgeTX + c]; }, ol, od);
+        else
+            edge_rule(gy, height, half, [&](int k) { return sL1[(rr + k) * kEdgeTX + c]; },
+                      [&](int k) { return sC[(rr + k) * EW + c + H]; }, [&](int k) { return sD1[(rr + k) * kEdgeTX + c]; },
+                      ol, od);
+        const size_t q = (size_t)gy * width + gx;
+        L2[q] = ol;
+        D2[q] = od;
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -800,19 +851,6 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
 int launch_ers_edge_phase(int width, int height, int dir, int window, const int32_t* color_labels, const int32_t* l0,
                           const float* d0, int32_t* l1, float* d1, hipStream_t s)
 {
-    const int H = window / 2 + 3;
-    const size_t lds0 = (size_t)(64 + 2 * H) * 4 * 12, lds1 = (size_t)(kEdgeScan1 + 2 * H) * 64 * 12;
-    if (window >= 0 && (dir == 0 ? lds0 : lds1) <= 64 * 1024) {
-        if (dir == 0)
-            hipLaunchKernelGGL(edge_phase_lds_kernel<0>, dim3(ceil_div(width, 64), ceil_div(height, 4)), dim3(256), lds0, s,
-                               width, height, window, color_labels, l0, d0, l1, d1);
-        else
-            hipLaunchKernelGGL(edge_phase_lds_kernel<1>, dim3(ceil_div(width, 64), ceil_div(height, kEdgeScan1)), dim3(256),
-                               lds1, s, width, height, window, color_labels, l0, d0, l1, d1);
-        KDE_HIP_TRY(hipGetLastError());
-        return KDE_OK;
-    }
-    // very wide search windows: the rule on global memory
     dim3 grid(ceil_div(width, 64), ceil_div(height, 4));
     if (dir == 0)
         hipLaunchKernelGGL(edge_phase_kernel<0>, grid, dim3(256), 0, s, width, height, window, color_labels, l0, d0, l1, d1);
@@ -820,6 +858,27 @@ int launch_ers_edge_phase(int width, int height, int dir, int window, const int3
         hipLaunchKernelGGL(edge_phase_kernel<1>, grid, dim3(256), 0, s, width, height, window, color_labels, l0, d0, l1, d1);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
+}
+
+// both phases; scratch_l / scratch_d hold the horizontal result only when the window is too wide for the fused kernel
+int launch_ers_edge_refining(int width, int height, int window, const int32_t* color_labels, const int32_t* l0,
+                             const float* d0, int32_t* scratch_l, float* scratch_d, int32_t* l2, float* d2, bool two_launches,
+                             hipStream_t s)
+{
+    const int H = window / 2 + 3;
+    const size_t ew = kEdgeTX + 2 * H, eh = kEdgeTY + 2 * H;
+    const size_t lds = ew * eh * 12 + (size_t)kEdgeTX * eh * 8;
+    if (!two_launches && window >= 0 && lds <= 64 * 1024) {
+        const dim3 grid(ceil_div(width, kEdgeTX), ceil_div(height, kEdgeTY));
+        if (window / 2 == 3)      // the reference's window (7): register-window form of the rule
+            hipLaunchKernelGGL(edge_fused_kernel<3>, grid, dim3(256), lds, s, width, height, window, color_labels, l0, d0, l2, d2);
+        else
+            hipLaunchKernelGGL(edge_fused_kernel<0>, grid, dim3(256), lds, s, width, height, window, color_labels, l0, d0, l2, d2);
+        KDE_HIP_TRY(hipGetLastError());
+        return KDE_OK;
+    }
+    KDE_TRY(launch_ers_edge_phase(width, height, 0, window, color_labels, l0, d0, scratch_l, scratch_d, s));
+    return launch_ers_edge_phase(width, height, 1, window, color_labels, scratch_l, scratch_d, l2, d2, s);
 }
 
 int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr, const int32_t* labels,

@@ -722,12 +722,11 @@ extern "C" int kde_ers_edge_refining(kde_ers* h, const int32_t* color_labels_dev
     hipStream_t s = as_stream(stream);
     const int W = h->width, H = h->height;
     // EdgeRefinedSuperpixel.cu:210-211 copies labels/depth, then edge_refining works in place; here the
-    // horizontal phase reads the caller's buffers and the vertical phase reads the horizontal result,
-    // so the two D2D copies disappear.
-    KDE_TRY(launch_ers_edge_phase(W, H, 0, kde_ers::WindowSize, color_labels_dev, depth_labels_dev, depth_dev,
-                                  h->labels_b.p, h->depth_b.p, s));
-    KDE_TRY(launch_ers_edge_phase(W, H, 1, kde_ers::WindowSize, color_labels_dev, h->labels_b.p, h->depth_b.p,
-                                  h->labels_a.p, h->depth_a.p, s));
+    // horizontal phase reads the caller's buffers and the vertical phase reads the horizontal result (kept in
+    // LDS by the fused kernel), so the two D2D copies disappear.
+    KDE_TRY(launch_ers_edge_refining(W, H, kde_ers::WindowSize, color_labels_dev, depth_labels_dev, depth_dev,
+                                     h->labels_b.p, h->depth_b.p, h->labels_a.p, h->depth_a.p,
+                                     /*two_launches=*/h->enhance_variant == 3, s));
     // depthmap_enhancement (.cu:220-221)
     KDE_TRY(launch_ers_enhance(W, H, h->depth_a.p, bgr_dev, h->labels_a.p, h->s_eff.p, h->table_host,
                                kde_ers::WindowSize, kde_ers::ColorSigma, kde_ers::DepthSigma, h->exp_zero,

@@ -183,6 +183,9 @@ int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3*
 
 int launch_ers_edge_phase(int width, int height, int dir, int window, const int32_t* color_labels, const int32_t* l0,
                           const float* d0, int32_t* l1, float* d1, hipStream_t s);
+int launch_ers_edge_refining(int width, int height, int window, const int32_t* color_labels, const int32_t* l0,
+                             const float* d0, int32_t* scratch_l, float* scratch_d, int32_t* l2, float* d2, bool two_launches,
+                             hipStream_t s);
 int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr, const int32_t* labels,
                        const float* s_eff, const float* table_host, int window, float color_sigma, float depth_sigma,
                        float exp_zero, float* out, int variant, hipStream_t s);
