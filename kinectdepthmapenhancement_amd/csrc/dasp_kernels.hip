@@ -213,12 +213,10 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
             for (int h = 0; h < 2; h++) {
                 const int tt = t + 8 * h;
                 const int rx = ccx - 2 + (tt & 3), ry = ccy - 2 + (tt >> 2);
-                id[h] = -1;
-                cd[h] = sd[h] = dd[h] = 0.0f;
-                if (rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows) {
-                    id[h] = ry * g.cols + rx;
-                    candidate(0, id[h], cd[h], sd[h], dd[h]);
-                }
+                const bool in = rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows;
+                // branch-free: an out-of-grid candidate evaluates cluster 0 and is discarded by the select below
+                candidate(0, in ? ry * g.cols + rx : 0, cd[h], sd[h], dd[h]);
+                id[h] = in ? ry * g.cols + rx : -1;
             }
 #pragma unroll
             for (int n = 0; n < NS; n++) {
@@ -268,16 +266,13 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
 #pragma unroll
         for (int t = 0; t < 16; t++) {
             const int rx = ccx - 2 + (t & 3), ry = ccy - 2 + (t >> 2);
-            if (rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows) {
-                const int id = ry * g.cols + rx;
-                float color_distance, spatial_distance, depth_distance;
-                candidate(n, id, color_distance, spatial_distance, depth_distance);
-                dist[t] = color_distance * cs.kc + spatial_distance * cs.ks + depth_distance * cs.kd;   // .cu:218
-                lab[t] = id;
-            } else {
-                dist[t] = cur.d;   // .cu:221-224
-                lab[t] = cur.l;
-            }
+            const bool in = rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows;
+            const int id = in ? ry * g.cols + rx : 0;            // branch-free, see above
+            float color_distance, spatial_distance, depth_distance;
+            candidate(n, id, color_distance, spatial_distance, depth_distance);
+            const float dnew = color_distance * cs.kc + spatial_distance * cs.ks + depth_distance * cs.kd;   // .cu:218
+            dist[t] = in ? dnew : cur.d;                          // .cu:221-224
+            lab[t] = in ? id : cur.l;
         }
         reduce_store(cs, dist, lab);
     }
