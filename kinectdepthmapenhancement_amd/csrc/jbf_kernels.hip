@@ -162,7 +162,10 @@ __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
     constexpr int LUT_N = (R * R + 1) * 766;
     constexpr int SEG = kPrePX + 2 * R;
     __shared__ float lut[LUT_N];
-    __shared__ uint32_t sc[LH * LW];
+    // rows are read as 16-byte vectors (4 pixels): LW * 4 bytes and the per-thread offset are multiples of 16, and
+    // consecutive lanes read consecutive vectors, which is bank-conflict free (dword reads at stride 4 are 8-way)
+    constexpr int LP = (LW + 3) / 4 * 4;                 // LDS row pitch
+    __shared__ __attribute__((aligned(16))) uint32_t sc[LH * LP + 4];
 
     const int tid = threadIdx.x;
     for (int i = tid; i < LUT_N; i += NT) lut[i] = a.lut[i];
@@ -171,22 +174,55 @@ __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
     const int total = tiles_per_frame * a.n;
     const int tx = tid % kPreBX, ty = tid / kPreBX;
 
+    // Staging slots of this thread (tile-independent LDS coordinates), and a register prefetch of the NEXT tile:
+    // its global loads are issued before the current tile is computed and are only waited for when they are
+    // written to LDS, so their latency hides behind the tap loop.
+    constexpr int NSLOT = (LW * LH + NT - 1) / NT;
+    int slot_x[NSLOT], slot_y[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+        const int i = tid + k * NT;
+        slot_y[k] = i / LW;
+        slot_x[k] = i - slot_y[k] * LW;
+    }
+    const size_t last_pix = (size_t)a.n * a.width * a.height - 1;     // its 4-byte read would leave the buffer
+    auto fetch = [&](int t, uint32_t* pre) {
+        const int frame_i = t / tiles_per_frame;
+        const int tile = t - frame_i * tiles_per_frame;
+        const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+        const size_t frame = (size_t)frame_i * a.width * a.height;
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) {
+            if (tid + k * NT < LW * LH) {
+                const int gx = reflect101(txi * kPreTW + slot_x[k] - R, a.width);
+                const int gy = reflect101(tyi * kPreTH + slot_y[k] - R, a.height);
+                const size_t pix = frame + (size_t)gy * a.width + gx;
+                if (pix < last_pix) {
+                    uint32_t v;
+                    __builtin_memcpy(&v, a.src + pix * 3, 4);          // one (unaligned) global_load_dword
+                    pre[k] = v & 0x00ffffffu;
+                } else {
+                    pre[k] = load_bgrx(a.src, pix);
+                }
+            }
+        }
+    };
+
+    uint32_t pre[NSLOT];
+    if ((int)blockIdx.x < total) fetch(blockIdx.x, pre);
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int frame_i = t / tiles_per_frame;
         const int tile = t - frame_i * tiles_per_frame;
         const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
         const int x0 = txi * kPreTW, y0 = tyi * kPreTH;
         const size_t frame = (size_t)frame_i * a.width * a.height;
-        const uint8_t* __restrict__ src = a.src + frame * 3;
 
         __syncthreads();   // previous tile fully consumed (also orders the LUT staging before first use)
-        for (int i = tid; i < LW * LH; i += NT) {
-            const int ly = i / LW, lx = i - ly * LW;
-            const int gx = reflect101(x0 + lx - R, a.width);
-            const int gy = reflect101(y0 + ly - R, a.height);
-            sc[i] = load_bgrx(src, (size_t)gy * a.width + gx);
-        }
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++)
+            if (tid + k * NT < LW * LH) sc[slot_y[k] * LP + slot_x[k]] = pre[k];
         __syncthreads();
+        if (t + (int)gridDim.x < total) fetch(t + gridDim.x, pre);
 
         const int xb = x0 + tx * kPrePX, y = y0 + ty;
         if (xb >= a.width || y >= a.height) continue;
@@ -197,17 +233,21 @@ __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
         pre_f2 sbg[kPrePX], srw[kPrePX];
 #pragma unroll
         for (int k = 0; k < kPrePX; k++) {
-            cc[k] = sc[(ty + R) * LW + tx * kPrePX + R + k];
+            cc[k] = sc[(ty + R) * LP + tx * kPrePX + R + k];
             sbg[k] = srw[k] = pre_f2{0.0f, 0.0f};
         }
 #pragma unroll
         for (int dy = -R; dy <= R; dy++) {
-            uint32_t v[SEG];
+            uint32_t v[(SEG + 3) / 4 * 4];
             pre_f2 fbg[SEG];
             float fr[SEG];
 #pragma unroll
+            for (int q4 = 0; q4 < (SEG + 3) / 4; q4++) {
+                const uint4 w = *reinterpret_cast<const uint4*>(&sc[(ty + R + dy) * LP + tx * kPrePX + 4 * q4]);
+                v[4 * q4] = w.x; v[4 * q4 + 1] = w.y; v[4 * q4 + 2] = w.z; v[4 * q4 + 3] = w.w;
+            }
+#pragma unroll
             for (int q = 0; q < SEG; q++) {
-                v[q] = sc[(ty + R + dy) * LW + tx * kPrePX + q];
                 fbg[q] = pre_f2{(float)(v[q] & 0xffu), (float)((v[q] >> 8) & 0xffu)};
                 fr[q] = (float)((v[q] >> 16) & 0xffu);
             }

@@ -11,12 +11,12 @@ OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 SHORT="bench.py --steps 3 --warmup 1 --cpu-seconds 0"
-rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc/fetch" -o fetch -- python3 $SHORT > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc/write" -o write -- python3 $SHORT > "$OUT/pmc_write.log" 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE -d "$OUT/pmc/sq" -o sq -- python3 $SHORT --no-extra > "$OUT/pmc_sq.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc/fetch" -o fetch -- python3 $SHORT > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc/write" -o write -- python3 $SHORT > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc/sq" -o sq -- python3 $SHORT --no-extra > "$OUT/pmc_sq.log" 2>&1
 python3 tools/collect_pmc.py --dir "$OUT/pmc" --out "$OUT/pmc_traffic.json" 2> "$OUT/pmc_summary.log"
 cp "$OUT/pmc_traffic.json" profiles/pmc_traffic.json
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- python3 bench.py --cpu-seconds 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 bench.py --cpu-seconds 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err"
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 find "$OUT/pmc" -name "*.csv" ! -name "*counter_collection.csv" -delete
 cat "$OUT/pmc_summary.log" "$OUT/bench.json"
