@@ -76,6 +76,7 @@ def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier):
         if evs:
             evs[2].record()
 
+    barrier()                                       # also brings the RCCL communicator up before anything is timed
     for _ in range(warmup):
         step()
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
@@ -85,8 +86,8 @@ def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier):
     for i in range(steps):
         step(evs[i])
     torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0                   # this rank's K steps, from the common start; MAX over ranks is taken
+    barrier()                                       # by the caller (the collective's own latency is not part of a step)
     k0 = [e[0].elapsed_time(e[1]) for e in evs]
     k1 = [e[1].elapsed_time(e[2]) for e in evs]
     return dt, k0, k1

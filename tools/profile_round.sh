@@ -20,3 +20,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats --
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 find "$OUT/pmc" -name "*.csv" ! -name "*counter_collection.csv" -delete
 cat "$OUT/pmc_summary.log" "$OUT/bench.json"
+# 4. BASELINE config 5 (full chain) per stage and per kernel, config 3 (tile sweep) and the other windows
+python3 tools/bench_chain.py > "$OUT/chain_config5_fhd.json" 2> "$OUT/chain.err"
+python3 tools/bench_chain.py --width 640 --height 480 > "$OUT/chain_config5_vga.json" 2>> "$OUT/chain.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/chain_stats" -o chain -- python3 tools/bench_chain.py > /dev/null 2>> "$OUT/chain.err"
+{
+  python3 tools/sweep_jbf.py --width 1920 --height 1080 --frames 8 --window 19 --with-generic
+  python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 19
+  python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 11 --with-generic
+  python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 7 --spatial-sigma 70 --color-sigma 50 --depth-sigma 20
+  python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 5 --spatial-sigma 70 --color-sigma 50 --depth-sigma 20 --with-generic
+} > "$OUT/sweep_k1_variants.log" 2> "$OUT/sweep.err"
+echo "profile round $TAG done"
