@@ -535,18 +535,17 @@ int launch_variant(const JbfLaunch& l, const FastArgs& fa, bool cskip, hipStream
 struct Variant {
     const char* name;
     int window;
-    bool separable_only;   // (unused: every variant takes the full table)
     bool packed;           // packed kernels read the table as (tap of p0, tap of p1) pairs per unit
     int (*launch)(const JbfLaunch&, const FastArgs&, bool, hipStream_t);
 };
 
 // name: w<window>-<pk|sc><pixels per thread>-<threads x>x<threads y>-<c = pass-1 arguments cached in registers | r = recomputed>
 #define V(WIN, PX, BX, BY, CACHE) \
-    {"w" #WIN "-sc" #PX "-" #BX "x" #BY "-" #CACHE, WIN, false, false, &launch_variant<WIN, PX, BX, BY, CACHE>}
+    {"w" #WIN "-sc" #PX "-" #BX "x" #BY "-" #CACHE, WIN, false, &launch_variant<WIN, PX, BX, BY, CACHE>}
 #define K(WIN, NP, BX, BY, CACHE) \
-    {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v4", WIN, false, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, true>}
+    {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v4", WIN, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, true>}
 #define KS(WIN, NP, BX, BY, CACHE) \
-    {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v1", WIN, false, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, false>}
+    {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v1", WIN, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, false>}
 const Variant kVariants[] = {
     // the FIRST variant listed for a window is the built-in choice (interleaved A/B sweep on MI355X,
     // profiles/r01_sweep_k1_variants.log); the others stay selectable for the tile sweep of BASELINE config 3
@@ -569,19 +568,11 @@ int jbf_fast_variant_count() { return kNumVariants; }
 const char* jbf_fast_variant_name(int v) { return (v >= 0 && v < kNumVariants) ? kVariants[v].name : "?"; }
 int jbf_fast_variant_window(int v) { return (v >= 0 && v < kNumVariants) ? kVariants[v].window : 0; }
 
-static bool table_has_zero(const JbfLaunch& l)
-{
-    for (int i = 0; i < l.window * l.window; i++)
-        if (l.table_host[i] == 0.0f) return true;
-    return false;
-}
-
 // first listed variant of a window that can serve the launch is the built-in choice
 int jbf_fast_default_variant(const JbfLaunch& l)
 {
-    const bool zero = table_has_zero(l);
     for (int v = 0; v < kNumVariants; v++)
-        if (kVariants[v].window == l.window && !(zero && kVariants[v].separable_only)) return v;
+        if (kVariants[v].window == l.window) return v;
     return -1;
 }
 
@@ -597,8 +588,6 @@ int launch_jbf_fast(const JbfLaunch& l, int variant, const float* table_host, hi
 {
     if (variant < 0 || variant >= kNumVariants || kVariants[variant].window != l.window)
         return fail(KDE_ERR_INVALID, "jbf: variant %d does not implement window %d", variant, l.window);
-    if (kVariants[variant].separable_only && table_has_zero(l))
-        return fail(KDE_ERR_INVALID, "jbf: variant %s needs a spatial table without underflowed (0) entries", kVariants[variant].name);
     FastArgs a;
     memset(&a, 0, sizeof(a));
     a.depth = l.depth;

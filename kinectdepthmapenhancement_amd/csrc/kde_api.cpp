@@ -10,14 +10,6 @@ namespace kde {
 // ---- errors ---------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "no error";
 
-void set_error(const char* fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-}
-
 int fail(int code, const char* fmt, ...)
 {
     va_list ap;

@@ -16,8 +16,7 @@
 namespace kde {
 
 // ---- error reporting -----------------------------------------------------------------------
-void set_error(const char* fmt, ...);
-int fail(int code, const char* fmt, ...);
+int fail(int code, const char* fmt, ...);   // records the message for kde_last_error_string() and returns code
 
 #define KDE_HIP_TRY(expr)                                                                     \
     do {                                                                                      \
