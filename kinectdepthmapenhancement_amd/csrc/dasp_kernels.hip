@@ -281,13 +281,25 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
 // ---- K8 analyzeClusters<256> (.cu:315-568) ---------------------------------------------------------
 __device__ __forceinline__ int f2i_rz(float v) { return (int)v; }   // v_cvt_i32_f32: RZ, saturating, NaN -> 0
 
+// One segmenter's view of analyzeClusters; blockIdx.z picks the segmenter (a pipeline updates both in one launch).
+// `labels` is the label map calculateLD writes next to its (distance, label) records -- the same labels at 4 bytes
+// per pixel, so one 16-byte access fetches four of them.
+struct AnalyzeSet {
+    const int32_t* labels;
+    kde_superpixel* mean;
+    kde_float3* centers;
+};
+struct AnalyzeSets {
+    AnalyzeSet s[2];
+};
+
 __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
-                                                              const kde_float3* __restrict__ pts,
-                                                              const kde_label_distance* __restrict__ ld,
-                                                              kde_superpixel* __restrict__ mean,
-                                                              kde_float3* __restrict__ centers,
+                                                              const kde_float3* __restrict__ pts, AnalyzeSets sets,
                                                               const float* __restrict__ intr)
 {
+    const int32_t* __restrict__ labels = sets.s[blockIdx.z].labels;
+    kde_superpixel* __restrict__ mean = sets.s[blockIdx.z].mean;
+    kde_float3* __restrict__ centers = sets.s[blockIdx.z].centers;
     __shared__ int si[7][256];     // r g b x y size npoints
     __shared__ float sf[3][256];   // X Y Z
     const int tid = threadIdx.x;
@@ -298,27 +310,81 @@ __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const
 
     int r_ = 0, g_ = 0, b_ = 0, x_ = 0, y_ = 0, s_ = 0, n_ = 0;
     float xf = 0.0f, yf = 0.0f, zf = 0.0f;
+    // The thread's rpx x rpy sub-window is walked in the reference's order (yy outer, xx inner; the float sums
+    // depend on it), but in chunks of CH positions whose loads are issued together: first the CH labels, then
+    // colour + point of the positions that belong to this cluster, then the accumulation: 2 load round trips per
+    // chunk instead of 2 per pixel.  (Staging the label test through LDS with coalesced row reads was measured
+    // slower: the kernel is bound by the strided gathers of the matched pixels, one cache line per lane.)
+    constexpr int CH = 8;
+    const size_t last_pix = (size_t)g.width * g.height - 1;    // its 4-byte colour read would leave the buffer
+    const int ax0 = m0.x + (tx - 8) * rpx, ay0 = m0.y + (ty - 8) * rpy;
+    // rows of the sub-window in the reference's order, CH positions at a time; labels are fetched four positions per
+    // 16-byte load (the kernel is bound by the NUMBER of per-lane cache-line accesses of its strided gathers, so
+    // bytes per access is what counts)
     for (int yy = 0; yy < rpy; yy++) {
-        for (int xx = 0; xx < rpx; xx++) {
-            const int arx = m0.x + (tx - 8) * rpx + xx;
-            const int ary = m0.y + (ty - 8) * rpy + yy;
-            if (arx >= 0 && arx < g.width && ary >= 0 && ary < g.height) {
-                const size_t q = (size_t)ary * g.width + arx;
-                if (ld[q].l == cluster_id) {
-                    r_ += (int)bgr[q * 3];
-                    g_ += (int)bgr[q * 3 + 1];
-                    b_ += (int)bgr[q * 3 + 2];
-                    x_ += arx;
-                    y_ += ary;
-                    s_ += 1;
-                    const kde_float3 pt = pts[q];
-                    xf += pt.x;
-                    yf += pt.y;
-                    zf += pt.z;
-                    n_ += pt.z > 50.0f ? 1 : 0;
+      const int ary = ay0 + yy;
+      const bool row_in = ary >= 0 && ary < g.height;
+      for (int xc = 0; xc < rpx; xc += CH) {
+        bool hit[CH];
+        size_t q[CH];
+        int px_[CH], py_[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k += 4) {
+            const int arx = ax0 + xc + k;
+            bool in[4];
+            bool all_in = true;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                in[j] = row_in && xc + k + j < rpx && arx + j >= 0 && arx + j < g.width;
+                all_in = all_in && in[j];
+                q[k + j] = in[j] ? (size_t)ary * g.width + arx + j : 0;
+                px_[k + j] = arx + j;
+                py_[k + j] = ary;
+            }
+            int l[4] = {-2, -2, -2, -2};               // never a cluster id
+            if (all_in) {
+                int4 w;
+                __builtin_memcpy(&w, &labels[q[k]], 16);
+                l[0] = w.x; l[1] = w.y; l[2] = w.z; l[3] = w.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (in[j]) l[j] = labels[q[k + j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) hit[k + j] = l[j] == cluster_id;
+        }
+        uint32_t col[CH];
+        kde_float3 pt[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            col[k] = 0;
+            pt[k] = kde_float3{0.0f, 0.0f, 0.0f};
+            if (hit[k]) {
+                if (q[k] < last_pix) {
+                    __builtin_memcpy(&col[k], bgr + q[k] * 3, 4);            // one (unaligned) dword load
+                } else {
+                    col[k] = (uint32_t)bgr[q[k] * 3] | ((uint32_t)bgr[q[k] * 3 + 1] << 8) | ((uint32_t)bgr[q[k] * 3 + 2] << 16);
                 }
+                pt[k] = pts[q[k]];
             }
         }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            if (hit[k]) {
+                r_ += (int)(col[k] & 0xffu);
+                g_ += (int)((col[k] >> 8) & 0xffu);
+                b_ += (int)((col[k] >> 16) & 0xffu);
+                x_ += px_[k];
+                y_ += py_[k];
+                s_ += 1;
+                xf += pt[k].x;
+                yf += pt[k].y;
+                zf += pt[k].z;
+                n_ += pt[k].z > 50.0f ? 1 : 0;
+            }
+        }
+      }
     }
     si[0][tid] = r_; si[1][tid] = g_; si[2][tid] = b_; si[3][tid] = x_; si[4][tid] = y_;
     si[5][tid] = s_; si[6][tid] = n_;
@@ -454,11 +520,25 @@ int launch_dasp_calc_ld_dual(const DaspGeom& g, const uint8_t* bgr, const kde_fl
     return launch_calc_sets<2>(g, bgr, pts, sets, first, s);
 }
 
-int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const kde_label_distance* ld,
+int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const int32_t* labels,
                         kde_superpixel* mean, kde_float3* centers, const float* intr_dev, hipStream_t s)
 {
-    hipLaunchKernelGGL(analyze_clusters_kernel, dim3(g.cols, g.rows), dim3(256), 0, s, g, bgr, pts, ld, mean, centers,
-                       intr_dev);
+    AnalyzeSets sets;
+    sets.s[0] = sets.s[1] = AnalyzeSet{labels, mean, centers};
+    hipLaunchKernelGGL(analyze_clusters_kernel, dim3(g.cols, g.rows, 1), dim3(256), 0, s, g, bgr, pts, sets, intr_dev);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
+
+// both segmenters of a pipeline in one launch (same geometry, colour, cloud and intrinsics)
+int launch_dasp_analyze_dual(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const int32_t* labels_a,
+                             kde_superpixel* mean_a, kde_float3* centers_a, const int32_t* labels_b, kde_superpixel* mean_b,
+                             kde_float3* centers_b, const float* intr_dev, hipStream_t s)
+{
+    AnalyzeSets sets;
+    sets.s[0] = AnalyzeSet{labels_a, mean_a, centers_a};
+    sets.s[1] = AnalyzeSet{labels_b, mean_b, centers_b};
+    hipLaunchKernelGGL(analyze_clusters_kernel, dim3(g.cols, g.rows, 2), dim3(256), 0, s, g, bgr, pts, sets, intr_dev);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }

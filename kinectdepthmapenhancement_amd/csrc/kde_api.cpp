@@ -612,7 +612,7 @@ extern "C" int kde_dasp_segmentation(kde_dasp* h, const uint8_t* bgr_dev, const 
         KDE_TRY(launch_dasp_calc_ld(h->g, bgr_dev, points_dev, h->ld.p, h->mean.p, h->centers.p, h->labels.p,
                                     color_sigma, spatial_sigma, depth_sigma, i == 0, s));
         if (h->skip_trailing_analyze && i == iteration - 1) break;
-        KDE_TRY(launch_dasp_analyze(h->g, bgr_dev, points_dev, h->ld.p, h->mean.p, h->centers.p, h->intr.p, s));
+        KDE_TRY(launch_dasp_analyze(h->g, bgr_dev, points_dev, h->labels.p, h->mean.p, h->centers.p, h->intr.p, s));
     }
     return KDE_OK;
 }
@@ -826,8 +826,9 @@ struct Pipeline {
             KDE_TRY(launch_dasp_calc_ld_dual(g, bgr, pts, SP->ld.p, SP->mean.p, SP->centers.p, SP->labels.p, sa, DASP->ld.p,
                                              DASP->mean.p, DASP->centers.p, DASP->labels.p, sb, i == 0, s));
             if (i == iters - 1) break;   // the trailing analyzeClusters is dead for the private segmenters
-            KDE_TRY(launch_dasp_analyze(g, bgr, pts, SP->ld.p, SP->mean.p, SP->centers.p, SP->intr.p, s));
-            KDE_TRY(launch_dasp_analyze(g, bgr, pts, DASP->ld.p, DASP->mean.p, DASP->centers.p, DASP->intr.p, s));
+            // both objects got the same intrinsics in SetParametor, so one launch updates both cluster sets
+            KDE_TRY(launch_dasp_analyze_dual(g, bgr, pts, SP->labels.p, SP->mean.p, SP->centers.p, DASP->labels.p,
+                                             DASP->mean.p, DASP->centers.p, SP->intr.p, s));
         }
         return kde_ers_edge_refining(ERS, SP->labels.p, DASP->labels.p, depth, bgr, stream);
     }

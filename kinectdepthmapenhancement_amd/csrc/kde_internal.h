@@ -177,8 +177,11 @@ int launch_dasp_calc_ld_dual(const DaspGeom& g, const uint8_t* bgr, const kde_fl
                              const kde_superpixel* mean_a, const kde_float3* centers_a, int32_t* labels_a,
                              const float sig_a[3], kde_label_distance* ld_b, const kde_superpixel* mean_b,
                              const kde_float3* centers_b, int32_t* labels_b, const float sig_b[3], bool first, hipStream_t s);
-int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const kde_label_distance* ld,
+int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const int32_t* labels,
                         kde_superpixel* mean, kde_float3* centers, const float* intr_dev, hipStream_t s);
+int launch_dasp_analyze_dual(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const int32_t* labels_a,
+                             kde_superpixel* mean_a, kde_float3* centers_a, const int32_t* labels_b, kde_superpixel* mean_b,
+                             kde_float3* centers_b, const float* intr_dev, hipStream_t s);
 
 int launch_ers_edge_phase(int width, int height, int dir, int window, const int32_t* color_labels, const int32_t* l0,
                           const float* d0, int32_t* l1, float* d1, hipStream_t s);

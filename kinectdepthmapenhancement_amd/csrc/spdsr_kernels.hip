@@ -66,7 +66,10 @@ __device__ void jacobi_eigen3(double A[3][3], double evals[3], double evecs[3][3
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int sweep = 0; sweep < 60; sweep++) {
         const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-        if (off == 0.0) break;
+        // converged to double precision (cyclic Jacobi converges quadratically: ~6 sweeps); waiting for an exact 0
+        // often runs all 60 sweeps on rounding noise and changes nothing a float normal can show
+        const double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off <= 1.0e-34 * diag) break;
         for (int p = 0; p < 2; p++)
             for (int q = p + 1; q < 3; q++) {
                 if (A[p][q] == 0.0) continue;
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void set_pseudo_depth_kernel(int npix, in
                                                                    const kde_float3* __restrict__ pts,
                                                                    const float2* __restrict__ nxy,
                                                                    kde_float3* __restrict__ plane_fitted,
-                                                                   kde_float3* __restrict__ optimized)
+                                                                   float* __restrict__ z0, float* __restrict__ pfz)
 {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= npix) return;
@@ -169,15 +172,22 @@ __global__ __launch_bounds__(kThreads) void set_pseudo_depth_kernel(int npix, in
         }
     }
     plane_fitted[i] = pf;
-    optimized[i] = p;                                 // the cudaMemcpy of .cu:281
+    // state of the mrf sweeps (see mrf_sweep_kernel): only z evolves, so the sweeps run on compact planes
+    z0[i] = p.z > 0.0f ? p.z : 0.0f;                  // optimized = input cloud (the cudaMemcpy of .cu:281); a z <= 0
+                                                      // or NaN can neither be a tap nor pass the centre test, like 0
+    pfz[i] = pf.z;
 }
 
+// mrf_optimization, Projection_GPU.cu:148-187 with (window 5, K 0.5, smooth_sigma 1.0), D5 (each sweep reads the
+// previous sweep's buffer).  Only the z of a point evolves (x, y = normalized ray * z whenever z is rewritten), so a
+// sweep reads and writes ONE float per pixel instead of two float3 (44 -> 12 B/px): the planes hold z, negated once
+// the pixel has been rewritten at least once (a rewritten z is a weighted mean of values > 50, never 0), and
+// mrf_expand_kernel turns the final plane back into points -- rewritten pixels as ray * z, the others untouched
+// from the input cloud, exactly what 20 in-place float3 sweeps leave behind.
 constexpr int kSwTX = 64, kSwTY = 4;
-__global__ __launch_bounds__(kThreads) void mrf_sweep_kernel(int width, int height, const kde_float3* __restrict__ in,
-                                                            const kde_float3* __restrict__ plane_fitted,
-                                                            const float2* __restrict__ nxy, kde_float3* __restrict__ out)
+__global__ __launch_bounds__(kThreads) void mrf_sweep_kernel(int width, int height, const float* __restrict__ zin,
+                                                            const float* __restrict__ pfz, float* __restrict__ zout)
 {
-    // mrf_optimization, Projection_GPU.cu:148-187 with (window 5, K 0.5, smooth_sigma 1.0)
     constexpr int R = 2, LW = kSwTX + 2 * R, LH = kSwTY + 2 * R;
     __shared__ float sz[LH * LW];
     const int x0 = blockIdx.x * kSwTX, y0 = blockIdx.y * kSwTY;
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void mrf_sweep_kernel(int width, int heig
         const int ly = i / LW, lx = i - ly * LW;
         const int gx = x0 + lx - R, gy = y0 + ly - R;
         float z = 0.0f;
-        if (gx >= 0 && gx < width && gy >= 0 && gy < height) z = in[(size_t)gy * width + gx].z;
+        if (gx >= 0 && gx < width && gy >= 0 && gy < height) z = fabsf(zin[(size_t)gy * width + gx]);
         sz[i] = z > 50.0f ? z : 0.0f;                 // taps need optimized.z > 50 (.cu:167)
     }
     __syncthreads();
@@ -193,16 +203,18 @@ __global__ __launch_bounds__(kThreads) void mrf_sweep_kernel(int width, int heig
     const int x = x0 + tx, y = y0 + ty;
     if (x >= width || y >= height) return;
     const size_t p = (size_t)y * width + x;
-    kde_float3 o = in[p];
-    const float pf = plane_fitted[p].z;
-    if (pf > 50.0f && fabsf(o.z - pf) < o.z * 0.01f) {
+    const float zs = zin[p];
+    float oz = fabsf(zs);
+    bool rewritten = zs < 0.0f;
+    const float pf = pfz[p];
+    if (pf > 50.0f && fabsf(oz - pf) < oz * 0.01f) {
         float numerator = pf, denominator = 1.0f;
 #pragma unroll
         for (int i = 0; i < 5; i++)
 #pragma unroll
             for (int j = 0; j < 5; j++) {
                 const float oq = sz[(ty + i) * LW + tx + j];
-                const float diff = fabsf(o.z - oq);
+                const float diff = fabsf(oz - oq);
                 // K / (1 + diff^2) * smooth_sigma with K = 0.5, smooth_sigma = 1; v_rcp_f32 (1 ulp) for the division
                 float filter = 0.5f * __builtin_amdgcn_rcpf(1.0f + diff * diff);
                 filter = oq > 0.0f ? filter : 0.0f;
@@ -210,14 +222,29 @@ __global__ __launch_bounds__(kThreads) void mrf_sweep_kernel(int width, int heig
                 denominator += filter;
             }
         if (denominator != 0.0f) {
-            const float depth = numerator / denominator;
-            const float2 r = nxy[p];
-            o.z = depth;
-            o.x = r.x * depth;
-            o.y = r.y * depth;
+            oz = numerator / denominator;
+            rewritten = true;
         }
     }
-    out[p] = o;
+    zout[p] = rewritten ? -oz : oz;
+}
+
+__global__ __launch_bounds__(kThreads) void mrf_expand_kernel(int npix, const float* __restrict__ zfinal,
+                                                             const kde_float3* __restrict__ pts,
+                                                             const float2* __restrict__ nxy, kde_float3* __restrict__ out)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= npix) return;
+    const float zs = zfinal[i];
+    kde_float3 o = pts[i];
+    if (zs < 0.0f) {
+        const float2 r = nxy[i];
+        const float depth = -zs;
+        o.z = depth;
+        o.x = r.x * depth;
+        o.y = r.y * depth;
+    }
+    out[i] = o;
 }
 
 }  // namespace
@@ -253,19 +280,25 @@ int launch_spdsr_plane_projection(int width, int height, int nclusters, const fl
                                   kde_float3* opt_b, int sweeps, kde_float3** result, hipStream_t s)
 {
     const int npix = width * height;
+    // opt_b (12 B/px) is carved into the three compact planes of the sweeps: z ping, z pong, plane-fitted z
+    float* zping = reinterpret_cast<float*>(opt_b);
+    float* zpong = zping + npix;
+    float* pfz = zpong + npix;
     hipLaunchKernelGGL(set_pseudo_depth_kernel, dim3(ceil_div(npix, kThreads)), dim3(kThreads), 0, s, npix, nclusters,
-                       reinterpret_cast<const float4*>(nd), labels, pts, reinterpret_cast<const float2*>(nxy), plane_fitted, opt_a);
-    kde_float3 *in = opt_a, *out = opt_b;
+                       reinterpret_cast<const float4*>(nd), labels, pts, reinterpret_cast<const float2*>(nxy), plane_fitted,
+                       zping, pfz);
+    float *in = zping, *out = zpong;
     dim3 grid(ceil_div(width, kSwTX), ceil_div(height, kSwTY));
     for (int i = 0; i < sweeps; i++) {
-        hipLaunchKernelGGL(mrf_sweep_kernel, grid, dim3(kThreads), 0, s, width, height, in, plane_fitted,
-                           reinterpret_cast<const float2*>(nxy), out);
-        kde_float3* t = in;
+        hipLaunchKernelGGL(mrf_sweep_kernel, grid, dim3(kThreads), 0, s, width, height, in, pfz, out);
+        float* t = in;
         in = out;
         out = t;
     }
+    hipLaunchKernelGGL(mrf_expand_kernel, dim3(ceil_div(npix, kThreads)), dim3(kThreads), 0, s, npix, in, pts,
+                       reinterpret_cast<const float2*>(nxy), opt_a);
     KDE_HIP_TRY(hipGetLastError());
-    *result = in;
+    *result = opt_a;
     return KDE_OK;
 }
 
