@@ -184,14 +184,33 @@ __global__ __launch_bounds__(kThreads) void set_pseudo_depth_kernel(int npix, in
 // the pixel has been rewritten at least once (a rewritten z is a weighted mean of values > 50, never 0), and
 // mrf_expand_kernel turns the final plane back into points -- rewritten pixels as ray * z, the others untouched
 // from the input cloud, exactly what 20 in-place float3 sweeps leave behind.
-constexpr int kSwTX = 64, kSwTY = 4;
-__global__ __launch_bounds__(kThreads) void mrf_sweep_kernel(int width, int height, const float* __restrict__ zin,
-                                                            const float* __restrict__ pfz, float* __restrict__ zout)
+// (Fusing several sweeps per launch through LDS with a halo was measured slower: the sweep is VALU-bound, and the
+// halo recomputation costs more than the saved traffic.  What pays is packed math: a thread owns two horizontally
+// adjacent pixels and every float op of the 25 taps is a v_pk_*_f32 on the pair -- see jbf_fast.hip for the unit
+// geometry -- with the "tap is valid" select folded into a {0, 0.5} factor prepared once per loaded LDS pair.)
+typedef float s_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s_f2 s_add_clamp(s_f2 a, s_f2 b)
 {
-    constexpr int R = 2, LW = kSwTX + 2 * R, LH = kSwTY + 2 * R;
-    __shared__ float sz[LH * LW];
-    const int x0 = blockIdx.x * kSwTX, y0 = blockIdx.y * kSwTY;
-    for (int i = threadIdx.x; i < LW * LH; i += kThreads) {
+    s_f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+constexpr int kSwBX = 32, kSwBY = 8;                  // threads; tile = 64 x 8 pixels
+__global__ __launch_bounds__(kSwBX* kSwBY) void mrf_sweep_kernel(int width, int height, const float* __restrict__ zin,
+                                                                const float* __restrict__ pfz, float* __restrict__ zout)
+{
+    constexpr int R = 2, WIN = 5, HALF = 2, TW = kSwBX * 2, TH = kSwBY, LW = TW + 2 * R, LH = TH + 2 * R;
+    __shared__ __attribute__((aligned(8))) float sz[LH * LW];
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int tx = threadIdx.x % kSwBX, ty = threadIdx.x / kSwBX;
+    const int x = x0 + 2 * tx, y = y0 + ty;
+    const bool own = x < width && y < height, has1 = own && x + 1 < width;
+    const size_t p = (size_t)y * width + x;
+    // this thread's own pixels first: their loads are in flight while the tile is staged (one round trip, not two)
+    const float zs0 = own ? zin[p] : 0.0f, zs1 = has1 ? zin[p + 1] : 0.0f;
+    const s_f2 pf = {own ? pfz[p] : 0.0f, has1 ? pfz[p + 1] : 0.0f};
+    for (int i = threadIdx.x; i < LW * LH; i += kSwBX * kSwBY) {
         const int ly = i / LW, lx = i - ly * LW;
         const int gx = x0 + lx - R, gy = y0 + ly - R;
         float z = 0.0f;
@@ -199,34 +218,55 @@ __global__ __launch_bounds__(kThreads) void mrf_sweep_kernel(int width, int heig
         sz[i] = z > 50.0f ? z : 0.0f;                 // taps need optimized.z > 50 (.cu:167)
     }
     __syncthreads();
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= width || y >= height) return;
-    const size_t p = (size_t)y * width + x;
-    const float zs = zin[p];
-    float oz = fabsf(zs);
-    bool rewritten = zs < 0.0f;
-    const float pf = pfz[p];
-    if (pf > 50.0f && fabsf(oz - pf) < oz * 0.01f) {
-        float numerator = pf, denominator = 1.0f;
+    if (!own) return;
+    s_f2 oz = {fabsf(zs0), fabsf(zs1)};
+    bool rw0 = zs0 < 0.0f, rw1 = zs1 < 0.0f;
+    const bool c0 = pf.x > 50.0f && fabsf(oz.x - pf.x) < oz.x * 0.01f;
+    const bool c1 = pf.y > 50.0f && fabsf(oz.y - pf.y) < oz.y * 0.01f;
+    if (c0 || c1) {
+        s_f2 num = pf, den = {1.0f, 1.0f};
+        const s_f2 one = {1.0f, 1.0f}, half = {0.5f, 0.5f};
 #pragma unroll
-        for (int i = 0; i < 5; i++)
+        for (int i = 0; i < WIN; i++) {
+            s_f2 q[3], hv[3];
 #pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const float oq = sz[(ty + i) * LW + tx + j];
-                const float diff = fabsf(oz - oq);
-                // K / (1 + diff^2) * smooth_sigma with K = 0.5, smooth_sigma = 1; v_rcp_f32 (1 ulp) for the division
-                float filter = 0.5f * __builtin_amdgcn_rcpf(1.0f + diff * diff);
-                filter = oq > 0.0f ? filter : 0.0f;
-                numerator = __builtin_fmaf(oq, filter, numerator);
-                denominator += filter;
+            for (int m = 0; m < 3; m++) {
+                q[m] = *reinterpret_cast<const s_f2*>(&sz[(ty + i) * LW + 2 * tx + 2 * m]);
+                hv[m] = s_add_clamp(q[m], q[m]) * half;             // 0.5 for a valid tap (z > 50), 0 otherwise
             }
-        if (denominator != 0.0f) {
-            oz = numerator / denominator;
-            rewritten = true;
+#pragma unroll
+            for (int u = 0; u < WIN; u++) {
+                // unit u = (tap of p0, tap of p1) out of ONE aligned pair: straight / swapped / leftover
+                s_f2 oq, h;
+                if (u <= HALF) {
+                    oq = q[u];
+                    h = hv[u];
+                } else if (u < WIN - 1) {
+                    oq = __builtin_shufflevector(q[u - HALF], q[u - HALF], 1, 0);
+                    h = __builtin_shufflevector(hv[u - HALF], hv[u - HALF], 1, 0);
+                } else {
+                    oq = s_f2{q[0].y, q[HALF].x};
+                    h = s_f2{hv[0].y, hv[HALF].x};
+                }
+                const s_f2 diff = oz - oq;
+                const s_f2 t1 = one + diff * diff;
+                // K / (1 + diff^2) * smooth_sigma with K = 0.5, smooth_sigma = 1; v_rcp_f32 (1 ulp) for the division
+                const s_f2 filter = s_f2{__builtin_amdgcn_rcpf(t1.x), __builtin_amdgcn_rcpf(t1.y)} * h;
+                num = __builtin_elementwise_fma(oq, filter, num);
+                den = den + filter;
+            }
+        }
+        if (c0 && den.x != 0.0f) {
+            oz.x = num.x / den.x;
+            rw0 = true;
+        }
+        if (c1 && den.y != 0.0f) {
+            oz.y = num.y / den.y;
+            rw1 = true;
         }
     }
-    zout[p] = rewritten ? -oz : oz;
+    zout[p] = rw0 ? -oz.x : oz.x;
+    if (has1) zout[p + 1] = rw1 ? -oz.y : oz.y;
 }
 
 __global__ __launch_bounds__(kThreads) void mrf_expand_kernel(int npix, const float* __restrict__ zfinal,
@@ -288,9 +328,9 @@ int launch_spdsr_plane_projection(int width, int height, int nclusters, const fl
                        reinterpret_cast<const float4*>(nd), labels, pts, reinterpret_cast<const float2*>(nxy), plane_fitted,
                        zping, pfz);
     float *in = zping, *out = zpong;
-    dim3 grid(ceil_div(width, kSwTX), ceil_div(height, kSwTY));
+    dim3 grid(ceil_div(width, kSwBX * 2), ceil_div(height, kSwBY));
     for (int i = 0; i < sweeps; i++) {
-        hipLaunchKernelGGL(mrf_sweep_kernel, grid, dim3(kThreads), 0, s, width, height, in, pfz, out);
+        hipLaunchKernelGGL(mrf_sweep_kernel, grid, dim3(kSwBX * kSwBY), 0, s, width, height, in, pfz, out);
         float* t = in;
         in = out;
         out = t;
