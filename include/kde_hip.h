@@ -255,6 +255,9 @@ int kde_spdsr_cluster_nd_device(kde_spdsr* h, float** out);                     
  * Measurement helpers (bench.py): a float4 streaming copy for the empirical HBM ceiling
  * ========================================================================================== */
 int kde_bench_copy(const void* src_dev, void* dst_dev, size_t bytes, void* stream);
+/* test hook: out_dev[i] = the kernels' square root of the integer first + i (i < n; first + n <= 2^24), so that the
+ * tests can prove it equal to sqrtf() on every argument calculateLD can form (DepthAdaptiveSuperpixel.cu:213) */
+int kde_test_sqrt_int24(uint32_t first, uint32_t n, float* out_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,19 @@ __global__ __launch_bounds__(64) void sample_clusters_kernel(DaspGeom g, const u
     }
 }
 
+// sqrtf() of an integer-valued float in [0, 2^24): v_rsq_f32 estimate, one Heron step on the exact fma residual.
+// The library sqrtf() spends 14 instructions (denormal scaling, two +-1 ulp probes, class test) to be correctly
+// rounded for every float; on this domain 6 are enough -- tests/test_gpu_dasp_ers.py checks ALL 2^24 arguments
+// against sqrtf bit for bit (px*px + py*py of pixel offsets, the only argument K7 has, is such an integer).
+__device__ __forceinline__ float sqrt_int24(float x)
+{
+    const float y = __builtin_amdgcn_rsqf(x);          // 1/sqrt(x), 1 ulp; +inf for x == 0
+    const float r = x * y;
+    const float e = __builtin_fmaf(-r, r, x);          // exact residual x - r^2
+    const float r1 = __builtin_fmaf(e, 0.5f * y, r);
+    return x == 0.0f ? 0.0f : r1;
+}
+
 // ---- K7 calculateLD<16> (.cu:167-313) -------------------------------------------------------------
 struct ClusterRec {   // LDS copy of one cluster: 32 B
     float r, g, b;
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
         const float e0 = c0 - mr, e1 = c1 - mg, e2 = c2 - mb;
         color_distance = e0 * e0 + e1 * e1 + e2 * e2;
         const float px = (float)(x - mx), py = (float)(y - my);
-        spatial_distance = sqrtf(px * px + py * py) * win2;
+        spatial_distance = sqrt_int24(px * px + py * py) * win2;
         depth_distance = 0.0f;
         if (z > 50.0f && cz > 50.0f) depth_distance = fabsf(z - cz);
     };
@@ -452,7 +465,21 @@ __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const
     }
 }
 
+// test hook: out[i] = sqrt_int24(first + i)
+__global__ __launch_bounds__(256) void sqrt_int24_probe_kernel(uint32_t first, uint32_t n, float* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] = sqrt_int24((float)(first + i));
+}
+
 }  // namespace
+
+int launch_sqrt_int24_probe(uint32_t first, uint32_t n, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(sqrt_int24_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, first, n, out);
+    KDE_HIP_TRY(hipGetLastError());
+    return KDE_OK;
+}
 
 int launch_dasp_sample(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
                        kde_float3* centers, hipStream_t s)

@@ -1032,3 +1032,11 @@ extern "C" int kde_bench_copy(const void* src_dev, void* dst_dev, size_t bytes, 
     KDE_REQUIRE(aligned16(src_dev) && aligned16(dst_dev), "kde_bench_copy: pointers must be 16-byte aligned");
     return launch_copy(src_dev, dst_dev, bytes, as_stream(stream));
 }
+
+extern "C" int kde_test_sqrt_int24(uint32_t first, uint32_t n, float* out_dev, void* stream)
+{
+    KDE_REQUIRE(out_dev, "kde_test_sqrt_int24: null argument");
+    KDE_REQUIRE((uint64_t)first + n <= (1ull << 24), "kde_test_sqrt_int24: arguments must stay below 2^24");
+    if (n == 0) return KDE_OK;
+    return launch_sqrt_int24_probe(first, n, out_dev, as_stream(stream));
+}

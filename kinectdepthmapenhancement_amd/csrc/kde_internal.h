@@ -168,6 +168,7 @@ int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
 struct DaspGeom {
     int width, height, rows, cols, wx, wy;
 };
+int launch_sqrt_int24_probe(uint32_t first, uint32_t n, float* out, hipStream_t s);
 int launch_dasp_sample(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
                        kde_float3* centers, hipStream_t s);
 int launch_dasp_calc_ld(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld,

@@ -325,3 +325,16 @@ def test_chain_is_hip_graph_capturable(torch_cuda, F, oracle, synth, frame):
     assert t.equal(rg.getRefinedLabels_Device(), rg2.getRefinedLabels_Device())
     assert t.equal(t.nan_to_num(rg.getRefinedDepth_Device()), t.nan_to_num(rg2.getRefinedDepth_Device()))
     assert not t.equal(rg.getRefinedLabels_Device(), eager_labels) or not t.equal(t.nan_to_num(eager_depth), t.nan_to_num(rg.getRefinedDepth_Device()))
+
+
+def test_k7_integer_sqrt_is_sqrtf_on_its_whole_domain(torch_cuda):
+    """calculateLD's spatial distance is sqrtf(px*px + py*py) of integer pixel offsets; the kernels compute it with a
+    6-instruction square root that is only claimed exact for integer arguments below 2^24 -- all of them are checked."""
+    from kinectdepthmapenhancement_amd import _native
+    lib = _native.lib()
+    n = 1 << 24
+    out = torch_cuda.empty(n, dtype=torch_cuda.float32, device="cuda")
+    _native.check(lib.kde_test_sqrt_int24(0, n, out.data_ptr(), torch_cuda.cuda.current_stream().cuda_stream))
+    got = out.cpu().numpy()
+    ref = np.sqrt(np.arange(n, dtype=np.float32))        # IEEE correctly rounded
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), int((got != ref).sum())
