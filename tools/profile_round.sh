@@ -32,3 +32,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/chain_stats" -o ch
   python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 5 --spatial-sigma 70 --color-sigma 50 --depth-sigma 20 --with-generic
 } > "$OUT/sweep_k1_variants.log" 2> "$OUT/sweep.err"
 echo "profile round $TAG done"
+# 5. SPDepthSuperResolution::Process (row f2)
+python3 tools/bench_spdsr.py > "$OUT/spdsr_fhd.json" 2> "$OUT/spdsr.err"
+python3 tools/bench_spdsr.py --width 640 --height 480 > "$OUT/spdsr_vga.json" 2>> "$OUT/spdsr.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/spdsr_stats" -o spdsr -- python3 tools/bench_spdsr.py > /dev/null 2>> "$OUT/spdsr.err"
+echo "spdsr done"
