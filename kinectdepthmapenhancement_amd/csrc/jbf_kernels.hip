@@ -463,8 +463,120 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
     return KDE_OK;
 }
 
+// --------------------------------------------------------------------------------------------
+// markov_random_field, tuned form for the reference's 5x5 window (any positive sigmas): the machinery of the
+// scalar K1 kernels (jbf_fast.hip) -- colour distance by v_dot4_u32_u8 on packed BGRX against a pre-biased
+// -|b|^2 plane whose invalid entries carry -1.7e38, weight = exp2(log2(smooth) - sigma_c*log2(e)*cd) with one
+// v_exp_f32 per tap, two horizontally adjacent pixels per thread.  There is no "factor == 0" rule in this
+// filter (MarkovRandomField.cu:27-31 multiplies unconditionally), and the centre enters with weight 1, so a
+// weight that underflows simply vanishes against a denominator >= 1.
+// --------------------------------------------------------------------------------------------
+struct MrfFastDev {
+    const float* depth;
+    const uint8_t* bgr;
+    float* out;
+    int width, height;
+    float kc;       // sigma_c * log2(e)
+    float lsm;      // log2(smooth_sigma) + 32 (-inf for smooth_sigma == 0): the taps are summed at 2^32 times their
+    float unscale;  // weight and scaled back once (2^-32), so weights in the denormal range are not flushed by v_exp_f32
+};
+
+constexpr int kMrfBX = 32, kMrfBY = 8, kMrfPX = 2;
+
+template <int WIN>
+__global__ __launch_bounds__(kMrfBX* kMrfBY) void mrf_fast_kernel(MrfFastDev a)
+{
+    constexpr int R = WIN / 2, NT = kMrfBX * kMrfBY, TW = kMrfBX * kMrfPX, TH = kMrfBY;
+    constexpr int LW = TW + 2 * R, LH = TH + 2 * R, SEG = kMrfPX + 2 * R;
+    constexpr uint32_t kMagicM = 0x4B000000u, kOffM = 1u << 18, kInvalidM = 0xFF000000u;
+    constexpr float kBiasM = 8388608.0f + 262144.0f;
+    __shared__ float s_d[LH * LW];
+    __shared__ uint32_t s_c[LH * LW];
+    __shared__ uint32_t s_n[LH * LW];
+
+    const size_t frame = (size_t)blockIdx.z * a.width * a.height;
+    const float* __restrict__ depth = a.depth + frame;
+    const uint8_t* __restrict__ bgr = a.bgr + frame * 3;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < LW * LH; i += NT) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gx = x0 + lx - R, gy = y0 + ly - R;
+        float d = 0.0f;
+        uint32_t c = 0;
+        if (gx >= 0 && gx < a.width && gy >= 0 && gy < a.height) {
+            const size_t q = (size_t)gy * a.width + gx;
+            d = depth[q];
+            c = load_bgrx(bgr, q);
+        }
+        const bool valid = d > 50.0f;
+        s_d[i] = valid ? d : 0.0f;
+        s_c[i] = c;
+        s_n[i] = valid ? (kMagicM + kOffM) - __builtin_amdgcn_udot4(c, c, 0u, false) : kInvalidM;
+    }
+    __syncthreads();
+
+    const int tx = tid % kMrfBX, ty = tid / kMrfBX;
+    const int xb = x0 + tx * kMrfPX, y = y0 + ty;
+    if (xb >= a.width || y >= a.height) return;
+    uint32_t cc[kMrfPX];
+    float negC[kMrfPX], num[kMrfPX], den[kMrfPX];
+#pragma unroll
+    for (int k = 0; k < kMrfPX; k++) {
+        cc[k] = s_c[(ty + R) * LW + tx * kMrfPX + R + k];
+        negC[k] = -(kBiasM + (float)__builtin_amdgcn_udot4(cc[k], cc[k], 0u, false));
+        num[k] = den[k] = 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < WIN; i++) {
+        float dr[SEG];
+        uint32_t cr[SEG], nr[SEG];
+#pragma unroll
+        for (int q = 0; q < SEG; q++) {
+            const int li = (ty + i) * LW + tx * kMrfPX + q;
+            dr[q] = s_d[li];
+            cr[q] = s_c[li];
+            nr[q] = s_n[li];
+        }
+#pragma unroll
+        for (int j = 0; j < WIN; j++)
+#pragma unroll
+            for (int k = 0; k < kMrfPX; k++) {
+                // bits of the float 2^23 + 2^18 + 2 a.b - |b|^2; adding negC gives -cd exactly (-1.7e38 if invalid)
+                const uint32_t u = (__builtin_amdgcn_udot4(cr[j + k], cc[k], 0u, false) << 1) + nr[j + k];
+                const float ncd = __uint_as_float(u) + negC[k];
+                const float f = __builtin_amdgcn_exp2f(__builtin_fmaf(ncd, a.kc, a.lsm));
+                num[k] = __builtin_fmaf(dr[j + k], f, num[k]);
+                den[k] += f;
+            }
+    }
+    float* __restrict__ o = a.out + frame + (size_t)y * a.width + xb;
+#pragma unroll
+    for (int k = 0; k < kMrfPX; k++)
+        if (xb + k < a.width) {
+            // the centre enters with weight 1 whatever its value (MarkovRandomField.cu:15)
+            const float n = __builtin_fmaf(num[k], a.unscale, depth[(size_t)y * a.width + xb + k]);
+            const float d = __builtin_fmaf(den[k], a.unscale, 1.0f);
+            o[k] = (d == 0.0f) ? 0.0f : n / d;
+        }
+}
+
 int launch_mrf(const MrfLaunch& a, hipStream_t s)
 {
+    // tuned kernel: the reference's window, both sigmas positive (color_sigma == 0 zeroes every tap in the reference)
+    if (a.window == 5 && a.color_sigma > 0.0f && a.smooth_sigma >= 0.0f && a.color_sigma < 1.0e30f && a.smooth_sigma < 1.0e30f) {
+        MrfFastDev f;
+        f.depth = a.depth; f.bgr = a.bgr; f.out = a.out; f.width = a.width; f.height = a.height;
+        f.kc = (float)((double)a.color_sigma * 1.4426950408889634);
+        const double lsm = a.smooth_sigma == 0.0f ? -INFINITY : std::log2((double)a.smooth_sigma);
+        const int off = lsm + 32.0 < 120.0 ? 32 : 0;
+        f.lsm = (float)(lsm + off);
+        f.unscale = (float)std::ldexp(1.0, -off);
+        dim3 fgrid(ceil_div(a.width, kMrfBX * kMrfPX), ceil_div(a.height, kMrfBY), a.n);
+        hipLaunchKernelGGL(mrf_fast_kernel<5>, fgrid, dim3(kMrfBX * kMrfBY), 0, s, f);
+        KDE_HIP_TRY(hipGetLastError());
+        return KDE_OK;
+    }
     MrfDev d{a.depth, a.bgr, a.out, a.width, a.height, a.window, a.color_sigma, a.smooth_sigma};
     const int R = a.window / 2;
     const size_t lds = (size_t)(kTileX + 2 * R) * (kTileY + 2 * R) * 8;

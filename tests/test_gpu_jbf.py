@@ -164,7 +164,37 @@ def test_mrf_sibling_filter(torch_cuda, F, oracle, frame):
     bgr, depth = frame(2, 320, 240)
     mrf = F.MarkovRandomField(320, 240)
     mrf.Process(dev(torch_cuda, depth), dev(torch_cuda, bgr))
-    assert_depth_close(host(mrf.getFiltered_Device()), oracle.mrf_kernel(depth, bgr), RTOL, what="MRF")
+    _assert_mrf_close(host(mrf.getFiltered_Device()), oracle.mrf_kernel(depth, bgr), "MRF")
+
+
+def _assert_mrf_close(got, ref, what):
+    """MRF bar: 1e-4 relative; outputs below 1e-30 mm (an invalid centre plus taps whose weight is a float denormal,
+    e.g. exp(-100) at the reference's ColorSigma = 50) are quantisation noise in ANY float32 evaluation and only
+    have to be that small as well."""
+    tiny = np.abs(ref) < 1e-30
+    assert np.all(np.abs(got[tiny]) < 1e-30), what
+    assert_depth_close(np.where(tiny, 0.0, got), np.where(tiny, 0.0, ref), RTOL, what=what)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(size=(320, 240), window=5, cs=0.002, ss=2.0),       # tuned kernel, weights that actually vary
+    dict(size=(203, 77), window=5, cs=0.0005, ss=150.0),     # ragged size, odd width (half-empty last pixel pair)
+    dict(size=(320, 240), window=5, cs=50.0, ss=0.0),        # smooth_sigma 0: every tap vanishes, output = input
+    dict(size=(160, 120), window=7, cs=0.002, ss=2.0),       # other windows: generic kernel
+    dict(size=(160, 120), window=5, cs=0.0, ss=2.0),         # color_sigma 0: generic kernel (taps get weight 0)
+])
+def test_mrf_other_parameters_and_batches(torch_cuda, F, oracle, synth, frame, cfg):
+    w, h = cfg["size"]
+    bgr, depth = synth.make_batch(40, 3, w, h)
+    depth[0][::7, ::5] = 0                                       # holes: the centre still enters with weight 1
+    mrf = F.MarkovRandomField(w, h, max_batch=3, window=cfg["window"], color_sigma=cfg["cs"], smooth_sigma=cfg["ss"])
+    out = torch_cuda.empty((3, h, w), dtype=torch_cuda.float32, device="cuda")
+    mrf.process_batch(dev(torch_cuda, depth), dev(torch_cuda, bgr), out)
+    for f in range(3):
+        ref = oracle.mrf_kernel(depth[f], bgr[f], cfg["window"], cfg["cs"], cfg["ss"])
+        _assert_mrf_close(host(out)[f], ref, f"MRF {cfg} frame {f}")
+    if cfg["ss"] == 0.0:
+        assert np.array_equal(host(out), depth)
 
 
 def test_errors_are_reported_not_fatal(torch_cuda, F):

@@ -37,3 +37,7 @@ python3 tools/bench_spdsr.py > "$OUT/spdsr_fhd.json" 2> "$OUT/spdsr.err"
 python3 tools/bench_spdsr.py --width 640 --height 480 > "$OUT/spdsr_vga.json" 2>> "$OUT/spdsr.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/spdsr_stats" -o spdsr -- python3 tools/bench_spdsr.py > /dev/null 2>> "$OUT/spdsr.err"
 echo "spdsr done"
+# 6. MarkovRandomField::Process (row f1)
+python3 tools/bench_mrf.py > "$OUT/mrf_vga.json" 2> "$OUT/mrf.err"
+python3 tools/bench_mrf.py --width 1920 --height 1080 --frames 8 > "$OUT/mrf_fhd.json" 2>> "$OUT/mrf.err"
+echo "mrf done"
