@@ -73,6 +73,15 @@ def main():
     pb = torch.empty((n, H, W, 3), dtype=torch.float32, device="cuda")
     ms = timed(torch, lambda: conv.projectiveToReal(db, pb), a.iters)
     res["p2r_batch"] = {"frames": n, "ms": ms, "GBs": 16.0 * n * px / ms / 1e6, "hbm_frac": 16.0 * n * px / ms / 1e6 / 8000}
+    # K3: the point-cloud forms (24 B/px) and the interpolating form of projectiveToReal (16 B/px)
+    qb = torch.empty_like(pb)
+    ms = timed(torch, lambda: conv.realToProjective(pb, qb), a.iters)
+    res["r2p_batch"] = {"frames": n, "ms": ms, "GBs": 24.0 * n * px / ms / 1e6, "hbm_frac": 24.0 * n * px / ms / 1e6 / 8000}
+    ms = timed(torch, lambda: conv.projectiveToReal(qb, pb), a.iters)
+    res["p2r_points_batch"] = {"frames": n, "ms": ms, "GBs": 24.0 * n * px / ms / 1e6, "hbm_frac": 24.0 * n * px / ms / 1e6 / 8000}
+    ms = timed(torch, lambda: conv.projectiveToRealInterp(db, pb), a.iters)
+    res["p2r_interp_batch"] = {"frames": n, "ms": ms, "GBs": 16.0 * n * px / ms / 1e6, "hbm_frac": 16.0 * n * px / ms / 1e6 / 8000}
+    del qb
     buf = F.Buffer2D(W, H)
     if (W * H) % 2 == 0:
         ms = timed(torch, lambda: buf.updateData(db), a.iters)
