@@ -83,3 +83,13 @@ def assert_depth_close(got, ref, rtol=1e-4, ill=None, max_bad=0, what="depth"):
         raise AssertionError(f"{what}: {nbad} pixels off (nan {int(bad_nan.sum())}, zero-mask "
                              f"{int(zero_mismatch.sum())}, max rel {rel.max():.3e}); first: {detail}")
     return float(rel.max())
+
+
+def assert_mrf_close(got, ref, what="MRF", rtol=1e-4):
+    """MRF bar: 1e-4 relative; outputs below 1e-30 mm (an invalid centre plus taps whose weight is a float denormal,
+    e.g. exp(-100) at the reference's ColorSigma = 50) are quantisation noise in ANY float32 evaluation -- the
+    oracle's own sums round to the denormal grid -- and only have to be that small as well."""
+    got, ref = np.asarray(got, np.float32), np.asarray(ref, np.float32)
+    tiny = np.abs(ref) < 1e-30
+    assert np.all(np.abs(got[tiny]) < 1e-30), what
+    assert_depth_close(np.where(tiny, 0.0, got), np.where(tiny, 0.0, ref), rtol, what=what)

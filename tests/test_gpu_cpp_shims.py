@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, assert_depth_close
+from conftest import ROOT, assert_depth_close, assert_mrf_close
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +33,7 @@ def test_main_replay_matches_oracle(torch_cuda, oracle, synth, color_fixture, tm
 
     jbf_ref, _, ill = oracle.jbf_process(depth, color_fixture, return_all=True)
     assert_depth_close(load("jbf"), jbf_ref, 1e-4, ill=ill, what="C++ JBF")
-    assert_depth_close(load("mrf"), oracle.mrf_kernel(depth, color_fixture), 1e-4, what="C++ MRF")
+    assert_mrf_close(load("mrf"), oracle.mrf_kernel(depth, color_fixture), "C++ MRF")
     with oracle.ers_flags((480, 640)) as rill:
         rg = oracle.rgbf_process(depth, oracle.p2r_depth(depth, K), color_fixture, 15, 20, K)
     assert_depth_close(load("rgbf"), rg["refined_depth"], 1e-4, ill=rill, what="C++ RGBF")

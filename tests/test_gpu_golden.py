@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, assert_depth_close
+from conftest import GOLDEN, assert_depth_close, assert_mrf_close
 from gpu_util import dev, host
 
 pytestmark = pytest.mark.gpu
@@ -39,4 +39,4 @@ def test_golden_crops(torch_cuda, synth):
     assert_depth_close(host(rg.getRefinedDepth_Device()), g["rgbf_refined_depth"], 1e-4, ill=g["rgbf_refined_depth_ill"], what="golden RGBF")
     mrf = F.MarkovRandomField(64, 48)
     mrf.Process(dev(t, cd), dev(t, cb))
-    assert_depth_close(host(mrf.getFiltered_Device()), g["mrf"], 1e-4, what="golden MRF")
+    assert_mrf_close(host(mrf.getFiltered_Device()), g["mrf"], "golden MRF")

@@ -6,7 +6,7 @@ ill-conditioned (every surviving weight denormal-scale) are excluded and must be
 import numpy as np
 import pytest
 
-from conftest import assert_depth_close
+from conftest import assert_depth_close, assert_mrf_close
 from gpu_util import dev, host
 
 pytestmark = pytest.mark.gpu
@@ -164,16 +164,7 @@ def test_mrf_sibling_filter(torch_cuda, F, oracle, frame):
     bgr, depth = frame(2, 320, 240)
     mrf = F.MarkovRandomField(320, 240)
     mrf.Process(dev(torch_cuda, depth), dev(torch_cuda, bgr))
-    _assert_mrf_close(host(mrf.getFiltered_Device()), oracle.mrf_kernel(depth, bgr), "MRF")
-
-
-def _assert_mrf_close(got, ref, what):
-    """MRF bar: 1e-4 relative; outputs below 1e-30 mm (an invalid centre plus taps whose weight is a float denormal,
-    e.g. exp(-100) at the reference's ColorSigma = 50) are quantisation noise in ANY float32 evaluation and only
-    have to be that small as well."""
-    tiny = np.abs(ref) < 1e-30
-    assert np.all(np.abs(got[tiny]) < 1e-30), what
-    assert_depth_close(np.where(tiny, 0.0, got), np.where(tiny, 0.0, ref), RTOL, what=what)
+    assert_mrf_close(host(mrf.getFiltered_Device()), oracle.mrf_kernel(depth, bgr), "MRF")
 
 
 @pytest.mark.parametrize("cfg", [
@@ -192,7 +183,7 @@ def test_mrf_other_parameters_and_batches(torch_cuda, F, oracle, synth, frame, c
     mrf.process_batch(dev(torch_cuda, depth), dev(torch_cuda, bgr), out)
     for f in range(3):
         ref = oracle.mrf_kernel(depth[f], bgr[f], cfg["window"], cfg["cs"], cfg["ss"])
-        _assert_mrf_close(host(out)[f], ref, f"MRF {cfg} frame {f}")
+        assert_mrf_close(host(out)[f], ref, f"MRF {cfg} frame {f}")
     if cfg["ss"] == 0.0:
         assert np.array_equal(host(out), depth)
 
