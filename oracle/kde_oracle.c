@@ -243,24 +243,40 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                             }
                         }
                     wa /= wt;
+                    /* second pass at the binary64 average and at the average moved by +-4 float32 ulps: a float32
+                     * implementation cannot know the first-pass average better than that, and where such a move
+                     * changes the result by more than 5e-5 (small depth sigma against large depths) the pixel
+                     * amplifies that rounding beyond the tolerance whatever the evaluation order */
+                    double res[3] = {0.0, 0.0, 0.0};
                     double nu = 0.0, de = 0.0;
-                    for (int i = -hw; i <= hw; i++)
-                        for (int j = -hw; j <= hw; j++) {
-                            int xj = x + j, yi = y + i;
-                            if (xj >= 0 && xj < width && yi >= 0 && yi < height &&
-                                depth[(size_t)yi * width + xj] > 50.0f) {
-                                double dq = (double)depth[(size_t)yi * width + xj];
-                                double cdv = (double)color_diff3(cc, guide + ((size_t)yi * width + xj) * 3);
-                                double f = 1.0;
-                                float sv = spatial[(i + hw) * window_size + (j + hw)];
-                                if (sv != 0.0f) f *= (double)sv;
-                                if (color_sigma != 0.0f && cdv / cden < xz) f *= exp(-cdv / cden);
-                                double xd = (dq - wa) * (dq - wa) / dden;
-                                if (depth_sigma != 0.0f && xd < xz) f *= exp(-xd);
-                                nu += dq * f;
-                                de += f;
+                    for (int pv = 0; pv < 3; pv++) {
+                        const double wap = wa * (1.0 + (double)(pv == 0 ? 0 : (pv == 1 ? 1 : -1)) * 4.0 * 1.1920928955078125e-7);
+                        double n2 = 0.0, d2 = 0.0;
+                        for (int i = -hw; i <= hw; i++)
+                            for (int j = -hw; j <= hw; j++) {
+                                int xj = x + j, yi = y + i;
+                                if (xj >= 0 && xj < width && yi >= 0 && yi < height &&
+                                    depth[(size_t)yi * width + xj] > 50.0f) {
+                                    double dq = (double)depth[(size_t)yi * width + xj];
+                                    double cdv = (double)color_diff3(cc, guide + ((size_t)yi * width + xj) * 3);
+                                    double f = 1.0;
+                                    float sv = spatial[(i + hw) * window_size + (j + hw)];
+                                    if (sv != 0.0f) f *= (double)sv;
+                                    if (color_sigma != 0.0f && cdv / cden < xz) f *= exp(-cdv / cden);
+                                    double xd = (dq - wap) * (dq - wap) / dden;
+                                    if (depth_sigma != 0.0f && xd < xz) f *= exp(-xd);
+                                    n2 += dq * f;
+                                    d2 += f;
+                                }
                             }
+                        res[pv] = d2 > 0.0 ? n2 / d2 : 0.0;
+                        if (pv == 0) {
+                            nu = n2;
+                            de = d2;
                         }
+                    }
+                    if (de > 0.0 && (fabs(res[1] - res[0]) > 5e-5 * fabs(res[0]) || fabs(res[2] - res[0]) > 5e-5 * fabs(res[0])))
+                        flag |= 4;
                     if (de > 0.0 && fabs((double)out - nu / de) > 2e-5 * fabs(nu / de)) flag |= 4;
                 }
                 ill[(size_t)y * width + x] = flag;
@@ -886,9 +902,12 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                     }
                 if (denominator == 0.0f) result = 0.0f;
                 else result = numerator / denominator;
+                /* every surviving weight is denormal-scale (a window straddling a depth step several DepthSigma
+                 * high): the ratio of two denormal sums has a few bits, in any float32 evaluation -- as in K1 */
+                if (denominator < 1e-30f) near_jump |= 4;
             }
             out[p] = result;
-            if (g_ers_flag_sink) g_ers_flag_sink[p] = near_jump ? 2 : 0;
+            if (g_ers_flag_sink) g_ers_flag_sink[p] = (uint8_t)(((near_jump & 1) ? 2 : 0) | ((near_jump & 4) ? 1 : 0));
         }
     }
 }

@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Randomised HIP-vs-oracle parity sweep (the oracle is the checker, as in tests/): random sizes, windows, sigmas,
+hole densities and scene seeds through K1 (every tuned window and the generic kernel), K0, MRF, and the
+RegionGrowingBilateralFilter pipeline (K6-K10; labels exact).  Prints one line per case and a summary; exit code 1
+on any violation.  Usage on the GPU box:  python tools/stress_parity.py --cases 200 --seed 1"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def run(cases=100, seed=1, dump=""):
+    """-> number of violations"""
+    a = argparse.Namespace(cases=cases, seed=seed, dump=dump)
+    import torch
+    from conftest import assert_depth_close, assert_mrf_close
+    from gpu_util import dev, host
+    from kinectdepthmapenhancement_amd import KdeError, filters as F, synth
+    from oracle import oracle as O
+    O.build()
+    O.set_threads(min(16, os.cpu_count() or 1))
+    rng = np.random.default_rng(a.seed)
+    bad = 0
+
+    def scene(w, h):
+        bgr, depth = synth.make_frame(int(rng.integers(1, 10 ** 6)), w, h)
+        mode = rng.integers(0, 4)
+        if mode == 1:                                   # heavy holes
+            depth = depth.copy()
+            depth[rng.random((h, w)) < rng.uniform(0.05, 0.6)] = 0
+        elif mode == 2:                                 # quantised colours: many cd == 0 / tiny cd taps
+            bgr = (bgr // 32 * 32).astype(np.uint8)
+        elif mode == 3:                                 # depth steps near the Q1 jump
+            depth = depth.copy()
+            depth[:, w // 2:] += np.float32(rng.uniform(200, 400))
+        return bgr, depth
+
+    state = {}
+    for case in range(a.cases):
+        state.clear()
+        kind = ["k1", "k1", "k1", "k0", "mrf", "rgbf"][int(rng.integers(0, 6))]
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 150))
+        try:
+            if kind == "k1":
+                win = int(rng.choice([1, 3, 5, 5, 7, 9, 11, 11, 13, 19, 21, 31]))
+                ss = float(rng.choice([0.5, 1.0, 3.0, 30.0, 70.0]))
+                cs = float(rng.choice([0.0, 2.0, 7.65, 20.0, 50.0, 400.0]))
+                ds = float(rng.choice([0.0, 5.0, 20.0, 70.0, 1000.0]))
+                bgr, depth = scene(w, h)
+                p = F.JointBilateralFilter.default_params()
+                p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma, p.presmooth = win, ss, cs, ds, 0
+                jbf = F.JointBilateralFilter(w, h, p)
+                names = F.JointBilateralFilter.variants()
+                cands = [-1, 0] + [v for v, nm in enumerate(names) if v and int(nm.split("-")[0][1:]) == win]
+                ref, ill = O.jbf_kernel(depth, bgr, win, ss, cs, ds, return_ill=True)
+                out = torch.empty((1, h, w), dtype=torch.float32, device="cuda")
+                state.update(bgr=bgr, depth=depth, ref=ref, ill=ill, params=np.array([win, ss, cs, ds]))
+                for v in cands:
+                    try:
+                        jbf.set_variant(v)
+                        jbf.filter_batch(dev(torch, depth[None]), dev(torch, bgr[None]), out)
+                    except KdeError:                    # a forced tuned variant may refuse a configuration
+                        if v > 0:
+                            continue
+                        raise
+                    state["got"] = host(out)[0].copy()
+                    state["variant"] = np.array([v])
+                    assert_depth_close(state["got"], ref, 1e-4, ill=ill, what=f"K1 v{v} win {win} sig {ss}/{cs}/{ds}")
+                desc = f"k1 {w}x{h} win {win} sig {ss}/{cs}/{ds} variants {len(cands)}"
+            elif kind == "k0":
+                ks = int(rng.choice([0, 3, 5, 7, 9]))
+                sc, sp = float(rng.choice([5.0, 30.0, 80.0])), float(rng.choice([1.7, 5.0, 30.0]))
+                bgr, depth = scene(w, h)
+                p = F.JointBilateralFilter.default_params()
+                p.presmooth_kernel_size, p.presmooth_sigma_color, p.presmooth_sigma_spatial = ks, sc, sp
+                if ks == 0 and int(round(sp * 1.5)) > 4:
+                    sp = 1.7
+                    p.presmooth_sigma_spatial = sp
+                jbf = F.JointBilateralFilter(w, h, p)
+                out = torch.empty((1, h, w, 3), dtype=torch.uint8, device="cuda")
+                jbf.presmooth_batch(dev(torch, bgr[None]), out)
+                assert np.array_equal(host(out)[0], O.cv_bilateral(bgr, ks, sc, sp)), "K0 bytes differ"
+                desc = f"k0 {w}x{h} ksize {ks} sig {sc}/{sp}"
+            elif kind == "mrf":
+                win = int(rng.choice([3, 5, 5, 5, 7]))
+                cs = float(rng.choice([0.0, 0.0005, 0.002, 0.05, 50.0]))
+                sm = float(rng.choice([0.0, 0.5, 2.0, 150.0]))
+                bgr, depth = scene(w, h)
+                mrf = F.MarkovRandomField(w, h, window=win, color_sigma=cs, smooth_sigma=sm)
+                mrf.Process(dev(torch, depth), dev(torch, bgr))
+                assert_mrf_close(host(mrf.getFiltered_Device()), O.mrf_kernel(depth, bgr, win, cs, sm), "MRF")
+                desc = f"mrf {w}x{h} win {win} sig {cs}/{sm}"
+            else:
+                w, h = int(rng.integers(40, 260)), int(rng.integers(30, 200))
+                rows, cols = int(rng.integers(2, max(3, h // 8))), int(rng.integers(2, max(3, w // 8)))
+                bgr, depth = scene(w, h)
+                K = synth.intrinsics(w, h)
+                pts = O.p2r_depth(depth, K)
+                rg = F.RegionGrowingBilateralFilter(w, h)
+                try:
+                    rg.SetParametor(rows, cols, K)
+                except Exception:
+                    print(f"[{case}] rgbf {w}x{h} grid {rows}x{cols}: geometry rejected (guard)")
+                    continue
+                from gpu_util import pts_as_f32
+                rg.Process(dev(torch, depth), dev(torch, pts_as_f32(pts)), dev(torch, bgr))
+                with O.ers_flags((h, w)) as ill:
+                    ref = O.rgbf_process(depth, pts, bgr, rows, cols, K)
+                assert np.array_equal(host(rg.getSPLabels_Device()), ref["sp_labels"]), "SP labels"
+                assert np.array_equal(host(rg.getDASPLabels_Device()), ref["dasp_labels"]), "DASP labels"
+                assert np.array_equal(host(rg.getRefinedLabels_Device()), ref["refined_labels"]), "refined labels"
+                state.update(bgr=bgr, depth=depth, ref=ref["refined_depth"], ill=ill, labels=ref["refined_labels"],
+                             params=np.array([rows, cols]), got=host(rg.getRefinedDepth_Device()).copy(),
+                             stage=host(rg.getEdgeStageDepth_Device()).copy() if hasattr(rg, "getEdgeStageDepth_Device") else np.zeros(1))
+                assert_depth_close(state["got"], ref["refined_depth"], 1e-4, ill=ill, what=f"RGBF depth grid {rows}x{cols}")
+                desc = f"rgbf {w}x{h} grid {rows}x{cols}"
+            print(f"[{case}] ok   {desc}", flush=True)
+        except AssertionError as e:
+            bad += 1
+            print(f"[{case}] FAIL {kind} {w}x{h}: {str(e)[:400]}", flush=True)
+            if a.dump and state:
+                os.makedirs(a.dump, exist_ok=True)
+                np.savez_compressed(os.path.join(a.dump, f"case{case}_{kind}.npz"), **state)
+    print(f"stress: {a.cases} cases, {bad} violations")
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--dump", default="", help="directory for the inputs / outputs of failing cases (npz)")
+    a = ap.parse_args()
+    sys.exit(1 if run(a.cases, a.seed, a.dump) else 0)
+
+
+if __name__ == "__main__":
+    main()
