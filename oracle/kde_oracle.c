@@ -227,7 +227,7 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                     const double cden = 2.0 * (double)color_sigma * (double)color_sigma;
                     const double dden = 2.0 * (double)depth_sigma * (double)depth_sigma;
                     const double xz = 103.97207708399179;
-                    double wa = 0.0, wt = 0.0;
+                    double wa = 0.0, wt = 0.0, wt2 = 0.0;
                     for (int i = -hw; i <= hw; i++)
                         for (int j = -hw; j <= hw; j++) {
                             int xj = x + j, yi = y + i;
@@ -240,17 +240,23 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                                 if (color_sigma != 0.0f && cdv / cden < xz) f *= exp(-cdv / cden);
                                 wa += (double)depth[(size_t)yi * width + xj] * f;
                                 wt += f;
+                                wt2 += f * f;
                             }
                         }
                     wa /= wt;
-                    /* second pass at the binary64 average and at the average moved by +-4 float32 ulps: a float32
-                     * implementation cannot know the first-pass average better than that, and where such a move
-                     * changes the result by more than 5e-5 (small depth sigma against large depths) the pixel
-                     * amplifies that rounding beyond the tolerance whatever the evaluation order */
+                    /* second pass at the binary64 average and at the average moved by +-eps: a float32 implementation
+                     * cannot know the first-pass average better than a few ulps plus the rounding of its sum over the
+                     * taps that carry weight.  Where such a move changes the result by more than
+                     * 1e-4 (small depth sigma against large depths), or flips the skip decision of a tap (the Q1 jump),
+                     * the pixel amplifies that rounding beyond the tolerance whatever the evaluation order. */
+                    /* rounding of a float32 sum grows with the number of taps that carry weight: the participation
+                     * ratio (sum w)^2 / sum w^2; measured 25 ulps at 128 equal weights -> 2.5 sqrt(n_eff) */
+                    const double n_eff = wt2 > 0.0 ? wt * wt / wt2 : 1.0;
+                    const double eps_avg = (4.0 + 2.5 * sqrt(n_eff)) * 1.1920928955078125e-7;
                     double res[3] = {0.0, 0.0, 0.0};
                     double nu = 0.0, de = 0.0;
                     for (int pv = 0; pv < 3; pv++) {
-                        const double wap = wa * (1.0 + (double)(pv == 0 ? 0 : (pv == 1 ? 1 : -1)) * 4.0 * 1.1920928955078125e-7);
+                        const double wap = wa * (1.0 + (double)(pv == 0 ? 0 : (pv == 1 ? 1 : -1)) * eps_avg);
                         double n2 = 0.0, d2 = 0.0;
                         for (int i = -hw; i <= hw; i++)
                             for (int j = -hw; j <= hw; j++) {
@@ -265,6 +271,10 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                                     if (color_sigma != 0.0f && cdv / cden < xz) f *= exp(-cdv / cden);
                                     double xd = (dq - wap) * (dq - wap) / dden;
                                     if (depth_sigma != 0.0f && xd < xz) f *= exp(-xd);
+                                    if (pv != 0 && depth_sigma != 0.0f) {
+                                        double x0d = (dq - wa) * (dq - wa) / dden;
+                                        if ((xd < xz) != (x0d < xz)) flag |= 2;
+                                    }
                                     n2 += dq * f;
                                     d2 += f;
                                 }
@@ -275,7 +285,7 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                             de = d2;
                         }
                     }
-                    if (de > 0.0 && (fabs(res[1] - res[0]) > 5e-5 * fabs(res[0]) || fabs(res[2] - res[0]) > 5e-5 * fabs(res[0])))
+                    if (de > 0.0 && (fabs(res[1] - res[0]) > 1e-4 * fabs(res[0]) || fabs(res[2] - res[0]) > 1e-4 * fabs(res[0])))
                         flag |= 4;
                     if (de > 0.0 && fabs((double)out - nu / de) > 2e-5 * fabs(nu / de)) flag |= 4;
                 }
@@ -863,6 +873,11 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                         }
                     }
                 if (count != 0) deviation /= (float)count;
+                /* Q6 is a discontinuity as well: a deviation of exactly 0 (adaptive sigma 0 -> 0/0 = NaN once the
+                 * decayed sigma has underflowed) and a deviation of one rounding error (finite result) are told apart
+                 * only by how (sum d*w)/(sum w) happens to round -- a single same-label tap is the extreme case.
+                 * Deviations within a few ulps of the average are flagged. */
+                if (deviation <= 16.0f * 1.1920929e-7f * fabsf(w_average)) near_jump |= 4;
                 /* filtering — .cu:158-200; the label test is commented out in the reference */
                 float numerator = 0.0f, denominator = 0.0f;
                 for (int i = -hw; i <= hw; i++)

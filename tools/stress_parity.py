@@ -43,7 +43,7 @@ def run(cases=100, seed=1, dump=""):
     state = {}
     for case in range(a.cases):
         state.clear()
-        kind = ["k1", "k1", "k1", "k0", "mrf", "rgbf"][int(rng.integers(0, 6))]
+        kind = ["k1", "k1", "k1", "k0", "mrf", "rgbf", "spdsr"][int(rng.integers(0, 7))]
         w, h = int(rng.integers(1, 200)), int(rng.integers(1, 150))
         try:
             if kind == "k1":
@@ -95,6 +95,42 @@ def run(cases=100, seed=1, dump=""):
                 mrf.Process(dev(torch, depth), dev(torch, bgr))
                 assert_mrf_close(host(mrf.getFiltered_Device()), O.mrf_kernel(depth, bgr, win, cs, sm), "MRF")
                 desc = f"mrf {w}x{h} win {win} sig {cs}/{sm}"
+            elif kind == "spdsr":
+                from gpu_util import pts_as_f32
+                w, h = int(rng.integers(48, 200)), int(rng.integers(40, 150))
+                rows, cols = int(rng.integers(2, max(3, h // 10))), int(rng.integers(2, max(3, w // 10)))
+                bgr, depth = scene(w, h)
+                K = synth.intrinsics(w, h)
+                pts = O.p2r_depth(depth, K)
+                sr = F.SPDepthSuperResolution(w, h)
+                try:
+                    sr.SetParametor(rows, cols, K)
+                except KdeError:
+                    print(f"[{case}] spdsr {w}x{h} grid {rows}x{cols}: geometry rejected (guard)")
+                    continue
+                sr.Process(dev(torch, depth), dev(torch, pts_as_f32(pts)), dev(torch, bgr))
+                with O.ers_flags((h, w)) as ill:
+                    rl, rd, _ = O.spdsr_head(depth, pts, bgr, rows, cols, K)
+                assert np.array_equal(host(sr.getRefinedLabels_Device()), rl), "SPDSR labels"
+                got = host(sr.getRefinedDepth_Device())
+                assert_depth_close(got, rd, 1e-4, ill=ill, what="SPDSR head depth")
+                gpts = host(sr.getEdgeEnhanced3DPoints_Device())
+                gp = np.ascontiguousarray(gpts).view(O.FLOAT3).reshape(h, w)
+                nd = host(sr.getClusterND_Device())
+                nd_ref = O.spdsr_cluster_planes(rl, gp, rows * cols)
+                has_plane = np.abs(nd_ref[:, 0]) < 1.0
+                # the smallest-eigenvalue direction is ill-defined for near-isotropic clusters: compare where it is not
+                okp = has_plane & (np.abs(nd[:, 0]) < 1.0)
+                assert np.array_equal(has_plane, np.abs(nd[:, 0]) < 1.0), "SPDSR plane / no-plane clusters"
+                close = np.isclose(nd[okp], nd_ref[okp], rtol=2e-4, atol=2e-4).all(axis=1)
+                assert close.mean() > 0.9, f"SPDSR planes: {int((~close).sum())} of {int(okp.sum())} differ"
+                # projection + 20 sweeps on the GPU's own planes (isolates the projection kernels from the eigen-solver)
+                pf_ref, opt_ref = O.projection_plane(nd, rl, gp, K, 20)
+                opt, ro = host(sr.getOptimizedPoints_Device()), pts_as_f32(opt_ref)
+                fin = np.isfinite(ro).all(-1) & np.isfinite(opt).all(-1)
+                assert_depth_close(opt[..., 2][fin], ro[..., 2][fin], 1e-4, what="SPDSR optimized z")
+                assert np.allclose(opt[fin], ro[fin], rtol=2e-4, atol=2e-2), "SPDSR optimized x/y"
+                desc = f"spdsr {w}x{h} grid {rows}x{cols}"
             else:
                 w, h = int(rng.integers(40, 260)), int(rng.integers(30, 200))
                 rows, cols = int(rng.integers(2, max(3, h // 8))), int(rng.integers(2, max(3, w // 8)))
