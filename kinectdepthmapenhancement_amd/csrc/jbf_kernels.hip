@@ -487,12 +487,12 @@ template <int WIN>
 __global__ __launch_bounds__(kMrfBX* kMrfBY) void mrf_fast_kernel(MrfFastDev a)
 {
     constexpr int R = WIN / 2, NT = kMrfBX * kMrfBY, TW = kMrfBX * kMrfPX, TH = kMrfBY;
-    constexpr int LW = TW + 2 * R, LH = TH + 2 * R, SEG = kMrfPX + 2 * R;
+    constexpr int LW = TW + 2 * R, LH = TH + 2 * R;
     constexpr uint32_t kMagicM = 0x4B000000u, kOffM = 1u << 18, kInvalidM = 0xFF000000u;
     constexpr float kBiasM = 8388608.0f + 262144.0f;
-    __shared__ float s_d[LH * LW];
-    __shared__ uint32_t s_c[LH * LW];
-    __shared__ uint32_t s_n[LH * LW];
+    __shared__ __attribute__((aligned(8))) float s_d[LH * LW];
+    __shared__ __attribute__((aligned(8))) uint32_t s_c[LH * LW];
+    __shared__ __attribute__((aligned(8))) uint32_t s_n[LH * LW];
 
     const size_t frame = (size_t)blockIdx.z * a.width * a.height;
     const float* __restrict__ depth = a.depth + frame;
@@ -519,36 +519,52 @@ __global__ __launch_bounds__(kMrfBX* kMrfBY) void mrf_fast_kernel(MrfFastDev a)
     const int tx = tid % kMrfBX, ty = tid / kMrfBX;
     const int xb = x0 + tx * kMrfPX, y = y0 + ty;
     if (xb >= a.width || y >= a.height) return;
-    uint32_t cc[kMrfPX];
-    float negC[kMrfPX], num[kMrfPX], den[kMrfPX];
+    // the pair of pixels of this thread in packed math (unit geometry of jbf_fast.hip: straight / swapped / leftover
+    // taps out of aligned LDS pairs; LW and the thread's first column are even)
+    static_assert(kMrfPX == 2 && LW % 2 == 0, "pair geometry");
+    constexpr int HALF = (WIN - 1) / 2, SEGP = 1 + R;
+    uint32_t cc[2];
+    pre_f2 negC, num = {0.0f, 0.0f}, den = {0.0f, 0.0f};
 #pragma unroll
-    for (int k = 0; k < kMrfPX; k++) {
-        cc[k] = s_c[(ty + R) * LW + tx * kMrfPX + R + k];
+    for (int k = 0; k < 2; k++) {
+        cc[k] = s_c[(ty + R) * LW + tx * 2 + R + k];
         negC[k] = -(kBiasM + (float)__builtin_amdgcn_udot4(cc[k], cc[k], 0u, false));
-        num[k] = den[k] = 0.0f;
     }
+    const pre_f2 kc2 = {a.kc, a.kc}, lsm2 = {a.lsm, a.lsm};
 #pragma unroll
     for (int i = 0; i < WIN; i++) {
-        float dr[SEG];
-        uint32_t cr[SEG], nr[SEG];
+        pre_f2 dp[SEGP];
+        uint2 cp[SEGP], np[SEGP];
 #pragma unroll
-        for (int q = 0; q < SEG; q++) {
-            const int li = (ty + i) * LW + tx * kMrfPX + q;
-            dr[q] = s_d[li];
-            cr[q] = s_c[li];
-            nr[q] = s_n[li];
+        for (int m = 0; m < SEGP; m++) {
+            const int li = (ty + i) * LW + tx * 2 + 2 * m;
+            dp[m] = *reinterpret_cast<const pre_f2*>(&s_d[li]);
+            cp[m] = *reinterpret_cast<const uint2*>(&s_c[li]);
+            np[m] = *reinterpret_cast<const uint2*>(&s_n[li]);
         }
 #pragma unroll
-        for (int j = 0; j < WIN; j++)
-#pragma unroll
-            for (int k = 0; k < kMrfPX; k++) {
-                // bits of the float 2^23 + 2^18 + 2 a.b - |b|^2; adding negC gives -cd exactly (-1.7e38 if invalid)
-                const uint32_t u = (__builtin_amdgcn_udot4(cr[j + k], cc[k], 0u, false) << 1) + nr[j + k];
-                const float ncd = __uint_as_float(u) + negC[k];
-                const float f = __builtin_amdgcn_exp2f(__builtin_fmaf(ncd, a.kc, a.lsm));
-                num[k] = __builtin_fmaf(dr[j + k], f, num[k]);
-                den[k] += f;
+        for (int u = 0; u < WIN; u++) {
+            uint32_t c0, c1, n0, n1;
+            pre_f2 dq;
+            if (u <= HALF) {
+                c0 = cp[u].x; c1 = cp[u].y; n0 = np[u].x; n1 = np[u].y; dq = dp[u];
+            } else if (u < WIN - 1) {
+                const int m = u - HALF;
+                c0 = cp[m].y; c1 = cp[m].x; n0 = np[m].y; n1 = np[m].x;
+                dq = __builtin_shufflevector(dp[m], dp[m], 1, 0);
+            } else {
+                c0 = cp[0].y; c1 = cp[HALF].x; n0 = np[0].y; n1 = np[HALF].x;
+                dq = pre_f2{dp[0].y, dp[HALF].x};
             }
+            // bits of the float 2^23 + 2^18 + 2 a.b - |b|^2; adding negC gives -cd exactly (-1.7e38 if invalid)
+            const uint32_t u0 = (__builtin_amdgcn_udot4(c0, cc[0], 0u, false) << 1) + n0;
+            const uint32_t u1 = (__builtin_amdgcn_udot4(c1, cc[1], 0u, false) << 1) + n1;
+            const pre_f2 ncd = pre_f2{__uint_as_float(u0), __uint_as_float(u1)} + negC;
+            const pre_f2 arg = __builtin_elementwise_fma(ncd, kc2, lsm2);
+            const pre_f2 f = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+            num = __builtin_elementwise_fma(dq, f, num);
+            den = den + f;
+        }
     }
     float* __restrict__ o = a.out + frame + (size_t)y * a.width + xb;
 #pragma unroll
