@@ -33,26 +33,50 @@ __global__ __launch_bounds__(kThreads) void cluster_moments_kernel(int npix, int
         __syncthreads();
     }
     double* out = COV ? cov : sums;
-    const int per_block = kThreads * 16;
-    const int begin = blockIdx.x * per_block;
-    const int end = begin + per_block < npix ? begin + per_block : npix;
-    for (int i = begin + threadIdx.x; i < end; i += kThreads) {
-        const int l = labels[i];
-        if (l < 0 || l >= nclusters) continue;       // label != -1 (SPDepthSuperResolution.cpp:70)
-        const kde_float3 p = pts[i];
-        double v[NV];
-        if (!COV) {
-            v[0] = 1.0; v[1] = (double)p.x; v[2] = (double)p.y; v[3] = (double)p.z;
-        } else {
-            const double n = sums[l * 4];
-            const double dx = (double)p.x - sums[l * 4 + 1] / n, dy = (double)p.y - sums[l * 4 + 2] / n,
-                         dz = (double)p.z - sums[l * 4 + 3] / n;
-            v[0] = dx * dx; v[1] = dx * dy; v[2] = dx * dz; v[3] = dy * dy; v[4] = dy * dz; v[5] = dz * dz;
-        }
-        double* dst = use_lds ? acc + l * NV : out + l * NV;
+    // a thread walks RUN consecutive pixels: superpixel labels change rarely along a row, so the moments of a run
+    // with one label are summed in registers and cost one set of atomics instead of one per pixel
+    constexpr int RUN = 8;
+    const int per_block = kThreads * RUN;
+    const int first = blockIdx.x * per_block + threadIdx.x * RUN;
+    double v[NV];
 #pragma unroll
-        for (int k = 0; k < NV; k++) atomicAdd(dst + k, v[k]);
+    for (int k = 0; k < NV; k++) v[k] = 0.0;
+    int cur = -1;                                      // label of the open run (-1: none)
+    auto flush = [&]() {
+        if (cur >= 0) {
+            double* dst = use_lds ? acc + cur * NV : out + cur * NV;
+#pragma unroll
+            for (int k = 0; k < NV; k++) atomicAdd(dst + k, v[k]);
+#pragma unroll
+            for (int k = 0; k < NV; k++) v[k] = 0.0;
+        }
+    };
+    double mx = 0.0, my = 0.0, mz = 0.0;               // COV: mean of the open run's cluster
+#pragma unroll
+    for (int r = 0; r < RUN; r++) {
+        const int i = first + r;
+        if (i >= npix) break;
+        const int l = labels[i];
+        if (l < 0 || l >= nclusters) continue;         // label != -1 (SPDepthSuperResolution.cpp:70)
+        if (l != cur) {
+            flush();
+            cur = l;
+            if (COV) {
+                const double n = sums[l * 4];
+                mx = sums[l * 4 + 1] / n;
+                my = sums[l * 4 + 2] / n;
+                mz = sums[l * 4 + 3] / n;
+            }
+        }
+        const kde_float3 p = pts[i];
+        if (!COV) {
+            v[0] += 1.0; v[1] += (double)p.x; v[2] += (double)p.y; v[3] += (double)p.z;
+        } else {
+            const double dx = (double)p.x - mx, dy = (double)p.y - my, dz = (double)p.z - mz;
+            v[0] += dx * dx; v[1] += dx * dy; v[2] += dx * dz; v[3] += dy * dy; v[4] += dy * dz; v[5] += dz * dz;
+        }
     }
+    flush();
     if (use_lds) {
         __syncthreads();
         for (int i = threadIdx.x; i < nclusters * NV; i += kThreads)
@@ -304,7 +328,7 @@ int launch_spdsr_cluster_planes(int width, int height, int nclusters, const int3
     KDE_HIP_TRY(hipMemsetAsync(sums, 0, (size_t)nclusters * 4 * sizeof(double), s));
     KDE_HIP_TRY(hipMemsetAsync(cov, 0, (size_t)nclusters * 6 * sizeof(double), s));
     const int use_lds = nclusters <= kMaxLdsClusters;
-    const int blocks = ceil_div(npix, kThreads * 16);
+    const int blocks = ceil_div(npix, kThreads * 8);
     hipLaunchKernelGGL(cluster_moments_kernel<false>, dim3(blocks), dim3(kThreads), use_lds ? (size_t)nclusters * 4 * 8 : 0, s,
                        npix, nclusters, use_lds, labels, pts, sums, cov);
     hipLaunchKernelGGL(cluster_moments_kernel<true>, dim3(blocks), dim3(kThreads), use_lds ? (size_t)nclusters * 6 * 8 : 0, s,
