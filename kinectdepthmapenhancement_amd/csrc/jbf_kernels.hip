@@ -138,8 +138,8 @@ __global__ __launch_bounds__(kThreads) void jbf_generic_kernel(JbfDev a)
 // [0,765]; the host tabulates it with the same float expression the CPU restatement uses, and the
 // accumulation order / fma / IEEE division are the same, so the u8 result is bit-identical by construction.
 //
-// Persistent workgroups: the 15 KB table is staged in LDS ONCE per workgroup, which then walks 64x16
-// tiles (4 horizontally adjacent pixels per thread; n1 by one v_sad_u8, channels by v_cvt_f32_ubyteN).
+// Persistent workgroups: the 15 KB table is staged in LDS ONCE per workgroup, which then walks 32x16
+// tiles (PX = 2 horizontally adjacent pixels per thread; n1 by one v_sad_u8, channels by v_cvt_f32_ubyteN).
 // Reflect-101 borders are resolved while staging the tile, so the tap loop has no bounds tests.
 // --------------------------------------------------------------------------------------------
 struct PreDev {
@@ -150,13 +150,16 @@ struct PreDev {
     int tiles_x, tiles_y;
 };
 
-constexpr int kPreBX = 16, kPreBY = 16, kPrePX = 4;
+constexpr int kPreBX = 16, kPreBY = 16;
 typedef float pre_f2 __attribute__((ext_vector_type(2)));
-constexpr int kPreTW = kPreBX * kPrePX, kPreTH = kPreBY;
+constexpr int kPreTH = kPreBY;
 
-template <int R>
+// PX = horizontally adjacent pixels per thread: 4 amortises the byte -> float conversions best, 2 halves the
+// registers (7 instead of 4 waves per SIMD) -- the kernel is latency-bound on its LDS table gathers
+template <int R, int PX>
 __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
 {
+    constexpr int kPrePX = PX, kPreTW = kPreBX * PX;
     constexpr int NT = kPreBX * kPreBY;
     constexpr int LW = kPreTW + 2 * R, LH = kPreTH + 2 * R;
     constexpr int LUT_N = (R * R + 1) * 766;
@@ -241,10 +244,18 @@ __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
             uint32_t v[(SEG + 3) / 4 * 4];
             pre_f2 fbg[SEG];
             float fr[SEG];
+            if (PX == 4) {
 #pragma unroll
-            for (int q4 = 0; q4 < (SEG + 3) / 4; q4++) {
-                const uint4 w = *reinterpret_cast<const uint4*>(&sc[(ty + R + dy) * LP + tx * kPrePX + 4 * q4]);
-                v[4 * q4] = w.x; v[4 * q4 + 1] = w.y; v[4 * q4 + 2] = w.z; v[4 * q4 + 3] = w.w;
+                for (int q4 = 0; q4 < (SEG + 3) / 4; q4++) {
+                    const uint4 w = *reinterpret_cast<const uint4*>(&sc[(ty + R + dy) * LP + tx * kPrePX + 4 * q4]);
+                    v[4 * q4] = w.x; v[4 * q4 + 1] = w.y; v[4 * q4 + 2] = w.z; v[4 * q4 + 3] = w.w;
+                }
+            } else {
+#pragma unroll
+                for (int q2 = 0; q2 < (SEG + 1) / 2; q2++) {
+                    const uint2 w = *reinterpret_cast<const uint2*>(&sc[(ty + R + dy) * LP + tx * kPrePX + 2 * q2]);
+                    v[2 * q2] = w.x; v[2 * q2 + 1] = w.y;
+                }
             }
 #pragma unroll
             for (int q = 0; q < SEG; q++) {
@@ -297,11 +308,16 @@ __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
             px[k] = sat(q[0]) | (sat(q[1]) << 8) | (sat(q[2]) << 16);
         }
         uint8_t* o = a.dst + (frame + (size_t)y * a.width + xb) * 3;
-        if ((a.width & 3) == 0 && xb + 3 < a.width && (reinterpret_cast<uintptr_t>(a.dst) & 3u) == 0) {
+        if (PX == 4 && (a.width & 3) == 0 && xb + 3 < a.width && (reinterpret_cast<uintptr_t>(a.dst) & 3u) == 0) {
             uint32_t* ow = reinterpret_cast<uint32_t*>(o);                  // 4 pixels = 12 bytes = 3 dwords
             ow[0] = px[0] | (px[1] << 24);
             ow[1] = (px[1] >> 8) | (px[2] << 16);
-            ow[2] = (px[2] >> 16) | (px[3] << 8);
+            ow[2] = (px[2] >> 16) | (px[3 % PX] << 8);
+        } else if (PX == 2 && xb + 1 < a.width && (reinterpret_cast<uintptr_t>(o) & 1u) == 0) {
+            uint16_t* oh = reinterpret_cast<uint16_t*>(o);                  // 2 pixels = 6 bytes = 3 halfwords
+            oh[0] = (uint16_t)(px[0] & 0xffffu);
+            oh[1] = (uint16_t)((px[0] >> 16) | ((px[1] & 0xffu) << 8));
+            oh[2] = (uint16_t)(px[1] >> 8);
         } else {
 #pragma unroll
             for (int k = 0; k < kPrePX; k++)
@@ -425,7 +441,8 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
     d.width = a.width;
     d.height = a.height;
     d.n = a.n;
-    d.tiles_x = ceil_div(a.width, kPreTW);
+    constexpr int kPX = 2;                                  // pixels per thread (A/B: 4)
+    d.tiles_x = ceil_div(a.width, kPreBX * kPX);
     d.tiles_y = ceil_div(a.height, kPreTH);
     const long long total = (long long)d.tiles_x * d.tiles_y * a.n;
     if (total > 0x7fffffffLL) return fail(KDE_ERR_INVALID, "presmooth: batch too large for one launch");
@@ -444,19 +461,19 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
     static long long slots[5] = {0, 0, 0, 0, 0};
     if (a.radius >= 1 && a.radius <= 4 && slots[a.radius] == 0) {
         switch (a.radius) {
-            case 1: slots[1] = resident(presmooth_kernel<1>); break;
-            case 2: slots[2] = resident(presmooth_kernel<2>); break;
-            case 3: slots[3] = resident(presmooth_kernel<3>); break;
-            default: slots[4] = resident(presmooth_kernel<4>); break;
+            case 1: slots[1] = resident(presmooth_kernel<1, kPX>); break;
+            case 2: slots[2] = resident(presmooth_kernel<2, kPX>); break;
+            case 3: slots[3] = resident(presmooth_kernel<3, kPX>); break;
+            default: slots[4] = resident(presmooth_kernel<4, kPX>); break;
         }
     }
     const long long cap = (a.radius >= 1 && a.radius <= 4) ? slots[a.radius] : 256;
     const unsigned grid = (unsigned)(total < cap ? total : cap);
     switch (a.radius) {
-        case 1: hipLaunchKernelGGL(presmooth_kernel<1>, dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
-        case 2: hipLaunchKernelGGL(presmooth_kernel<2>, dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
-        case 3: hipLaunchKernelGGL(presmooth_kernel<3>, dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
-        case 4: hipLaunchKernelGGL(presmooth_kernel<4>, dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
+        case 1: hipLaunchKernelGGL((presmooth_kernel<1, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
+        case 2: hipLaunchKernelGGL((presmooth_kernel<2, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
+        case 3: hipLaunchKernelGGL((presmooth_kernel<3, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
+        case 4: hipLaunchKernelGGL((presmooth_kernel<4, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
         default: return fail(KDE_ERR_UNSUPPORTED, "presmooth: radius %d not built", a.radius);
     }
     KDE_HIP_TRY(hipGetLastError());
