@@ -186,79 +186,87 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
         depth_distance = 0.0f;
         if (z > 50.0f && cz > 50.0f) depth_distance = fabsf(z - cz);
     };
-    // 16-way tree argmin with the reference's strict '>' (.cu:226-305), then the invalid-depth rule (.cu:308-312)
-    auto reduce_store = [&](const CalcSet& cs, float* dist, int* lab) {
-#pragma unroll
-        for (int step = 8; step >= 1; step >>= 1) {
-#pragma unroll
-            for (int t = 0; t < step; t++) {
-                if (dist[t] > dist[t + step]) {
-                    lab[t] = lab[t + step];
-                    dist[t] = dist[t + step];
-                }
-            }
-        }
-        kde_label_distance o;
-        o.l = lab[0];
-        o.d = dist[0];
-        if (z < 50.0f && cs.depth_on) {
-            o.l = -1;
-            o.d = 0.0f;
-        }
-        cs.ld[p] = o;
-        cs.labels[p] = o.l;
-    };
-
-    if (FIRST) {
-        kde_label_distance cur;                                   // init_LD (.cu:3-14)
-        cur.l = (y / g.wy) * g.cols + (x / g.wx);
-        cur.d = 999999.9f;
+    // The reference reduces the 16 candidate distances with a tree of strict '>' comparisons (.cu:226-305): the
+    // minimum wins, and among equal minima the one whose index is first in BIT-REVERSED order (0, 8, 4, 12, 2, ...).
+    // A scan in that order with a strict '<' is the same function -- and lets candidates be skipped: the pixel's own
+    // grid cell (candidate 10) is evaluated first, and a cluster whose spatial term ALONE exceeds that distance (with
+    // a 1e-5 margin; colour and depth terms are >= 0) can neither win nor tie.  The skip is taken when no lane of
+    // the wavefront needs the candidate; typically 5 of 16 are evaluated.  Segmenters lo..hi share table `tab` and
+    // the previous assignment `cur` (all of them in the FIRST step, one at a time later).
+    auto assign = [&](int tab, int lo, int hi, const kde_label_distance cur) {
         const int ccx = cur.l % g.cols, ccy = cur.l / g.cols;
-        // candidates t and t + 8 are generated together and meet in the first level of the tree at once, so only
-        // 8 (distance, label) entries per segmenter stay live
-        float dist[NS][8];
-        int lab[NS][8];
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-            float cd[2], sd[2], dd[2];
-            int id[2];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int tt = t + 8 * h;
-                const int rx = ccx - 2 + (tt & 3), ry = ccy - 2 + (tt >> 2);
-                const bool in = rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows;
-                // branch-free: an out-of-grid candidate evaluates cluster 0 and is discarded by the select below
-                candidate(0, in ? ry * g.cols + rx : 0, cd[h], sd[h], dd[h]);
-                id[h] = in ? ry * g.cols + rx : -1;
-            }
+        auto grid_id = [&](int t) {
+            const int rx = ccx - 2 + (t & 3), ry = ccy - 2 + (t >> 2);
+            return (rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows) ? ry * g.cols + rx : -1;
+        };
+        float best[NS], thr[NS], own_d[NS];
+        int bl[NS];
+        const int own_id = grid_id(10);
+        {
+            float cdv = 0.0f, sdv = 0.0f, ddv = 0.0f;
+            candidate(tab, own_id >= 0 ? own_id : 0, cdv, sdv, ddv);
 #pragma unroll
             for (int n = 0; n < NS; n++) {
+                if (n < lo || n > hi) continue;
                 const CalcSet& cs = sets.s[n];
-                // .cu:218 for a cluster inside the grid, :221-224 (previous assignment) otherwise
-                const float d_lo = id[0] >= 0 ? cd[0] * cs.kc + sd[0] * cs.ks + dd[0] * cs.kd : cur.d;
-                const float d_hi = id[1] >= 0 ? cd[1] * cs.kc + sd[1] * cs.ks + dd[1] * cs.kd : cur.d;
-                const int l_lo = id[0] >= 0 ? id[0] : cur.l, l_hi = id[1] >= 0 ? id[1] : cur.l;
-                const bool take = d_lo > d_hi;             // tree level "step 8", strict '>'
-                dist[n][t] = take ? d_hi : d_lo;
-                lab[n][t] = take ? l_hi : l_lo;
+                own_d[n] = cdv * cs.kc + sdv * cs.ks + ddv * cs.kd;                  // .cu:218
+                // spatial term of a candidate = sqrt(n2) * win2 * ks > own_d * (1 + 1e-5)  <=>  n2 > thr
+                const float q = own_d[n] * 1.00001f / (win2 * cs.ks);
+                thr[n] = (own_id >= 0 && cs.ks > 0.0f && own_d[n] >= 0.0f) ? q * q : INFINITY;
+                best[n] = INFINITY;
+                bl[n] = cur.l;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int t = ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);   // bit-reversed scan
+            const int id = grid_id(t);
+            if (t == 10 || id < 0) {
+#pragma unroll
+                for (int n = 0; n < NS; n++) {
+                    if (n < lo || n > hi) continue;
+                    const float d = id < 0 ? cur.d : own_d[n];                    // .cu:221-224 outside the grid
+                    const int l = id < 0 ? cur.l : id;
+                    const bool take = d < best[n];
+                    best[n] = take ? d : best[n];
+                    bl[n] = take ? l : bl[n];
+                }
+                continue;
+            }
+            int mx, my;
+            if (USE_LDS) {
+                mx = recs[tab * nclusters + id].x;
+                my = recs[tab * nclusters + id].y;
+            } else {
+                mx = sets.s[tab].mean[id].x;
+                my = sets.s[tab].mean[id].y;
+            }
+            const float px = (float)(x - mx), py = (float)(y - my);
+            const float n2 = px * px + py * py;
+            bool need = false;
+#pragma unroll
+            for (int n = 0; n < NS; n++)
+                if (n >= lo && n <= hi) need |= !(n2 > thr[n]);
+            if (__builtin_amdgcn_ballot_w64(need) == 0) continue;              // nobody in the wavefront needs it
+            float cdv, sdv, ddv;
+            candidate(tab, id, cdv, sdv, ddv);
+#pragma unroll
+            for (int n = 0; n < NS; n++) {
+                if (n < lo || n > hi) continue;
+                const CalcSet& cs = sets.s[n];
+                const float d = cdv * cs.kc + sdv * cs.ks + ddv * cs.kd;          // .cu:218
+                const bool take = d < best[n];
+                best[n] = take ? d : best[n];
+                bl[n] = take ? id : bl[n];
             }
         }
 #pragma unroll
         for (int n = 0; n < NS; n++) {
+            if (n < lo || n > hi) continue;
             const CalcSet& cs = sets.s[n];
-#pragma unroll
-            for (int step = 4; step >= 1; step >>= 1) {
-#pragma unroll
-                for (int t = 0; t < step; t++) {
-                    if (dist[n][t] > dist[n][t + step]) {
-                        lab[n][t] = lab[n][t + step];
-                        dist[n][t] = dist[n][t + step];
-                    }
-                }
-            }
             kde_label_distance o;
-            o.l = lab[n][0];
-            o.d = dist[n][0];
+            o.l = bl[n];
+            o.d = best[n];
             if (z < 50.0f && cs.depth_on) {   // .cu:308-312
                 o.l = -1;
                 o.d = 0.0f;
@@ -266,29 +274,17 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
             cs.ld[p] = o;
             cs.labels[p] = o.l;
         }
+    };
+
+    if (FIRST) {
+        kde_label_distance cur;                                   // init_LD (.cu:3-14)
+        cur.l = (y / g.wy) * g.cols + (x / g.wx);
+        cur.d = 999999.9f;
+        assign(0, 0, NS - 1, cur);
         return;
     }
-
 #pragma unroll
-    for (int n = 0; n < NS; n++) {
-        const CalcSet& cs = sets.s[n];
-        const kde_label_distance cur = cs.ld[p];
-        const int ccx = cur.l % g.cols, ccy = cur.l / g.cols;
-        float dist[16];
-        int lab[16];
-#pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int rx = ccx - 2 + (t & 3), ry = ccy - 2 + (t >> 2);
-            const bool in = rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows;
-            const int id = in ? ry * g.cols + rx : 0;            // branch-free, see above
-            float color_distance, spatial_distance, depth_distance;
-            candidate(n, id, color_distance, spatial_distance, depth_distance);
-            const float dnew = color_distance * cs.kc + spatial_distance * cs.ks + depth_distance * cs.kd;   // .cu:218
-            dist[t] = in ? dnew : cur.d;                          // .cu:221-224
-            lab[t] = in ? id : cur.l;
-        }
-        reduce_store(cs, dist, lab);
-    }
+    for (int n = 0; n < NS; n++) assign(n, n, n, sets.s[n].ld[p]);
 }
 
 // ---- K8 analyzeClusters<256> (.cu:315-568) ---------------------------------------------------------

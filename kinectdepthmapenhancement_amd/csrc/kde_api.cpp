@@ -604,6 +604,8 @@ extern "C" int kde_dasp_segmentation(kde_dasp* h, const uint8_t* bgr_dev, const 
     KDE_REQUIRE(h && bgr_dev && points_dev, "kde_dasp_segmentation: null argument");
     KDE_REQUIRE(h->set, "kde_dasp_segmentation: SetParametor was not called");
     KDE_REQUIRE(iteration >= 0, "kde_dasp_segmentation: negative iteration count");
+    // the weights are (sigma / sum of sigmas)^2 (.cu:209-217): a zero sum is 0/0 in the reference
+    KDE_REQUIRE(spatial_sigma + color_sigma + depth_sigma != 0.0f, "kde_dasp_segmentation: the sigmas must not sum to zero");
     hipStream_t s = as_stream(stream);
     // DepthAdaptiveSuperpixel.cu:570-586
     // init_LD (K5) is folded into the first calculateLD: its output is only ever read there

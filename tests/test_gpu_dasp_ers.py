@@ -338,3 +338,27 @@ def test_k7_integer_sqrt_is_sqrtf_on_its_whole_domain(torch_cuda):
     got = out.cpu().numpy()
     ref = np.sqrt(np.arange(n, dtype=np.float32))        # IEEE correctly rounded
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), int((got != ref).sum())
+
+
+@pytest.mark.parametrize("sig", [(100.0, 0.0, 0.0), (100.0, 0.0, 50.0), (0.0, 0.0, 200.0)])
+def test_k7_tie_break_follows_the_reference_tree(torch_cuda, F, oracle, synth, sig):
+    """With a constant colour image and no spatial term every in-grid candidate has the same distance: the label is
+    decided by the tie-break of the reference's 16-way tree (strict '>' at every level = bit-reversed index order),
+    which the kernel reproduces with a scan in that order -- including after analyzeClusters moved the centres."""
+    w, h = 160, 120
+    _, depth = synth.make_frame(3, w, h)
+    depth = (np.round(depth / 500.0) * 500.0).astype(np.float32)          # few distinct depths: ties in the depth term too
+    bgr = np.full((h, w, 3), 77, np.uint8)
+    K = synth.intrinsics(w, h)
+    pts = oracle.p2r_depth(depth, K)
+    for it in (1, 3):
+        d = F.DepthAdaptiveSuperpixel(w, h)
+        d.SetParametor(6, 8, K)
+        d.Segmentation(dev(torch_cuda, bgr), dev(torch_cuda, pts_as_f32(pts)), *sig, it)
+        labels, ld, mean, centers = oracle.dasp_segmentation(bgr, pts, 6, 8, K, *sig, it)
+        assert np.array_equal(host(d.getLabelDevice()), labels), (sig, it)
+        gl = ld_records(d.getLDDevice())
+        assert np.array_equal(gl["l"], ld["l"]) and np.array_equal(gl["d"], ld["d"])
+        assert len(np.unique(labels)) > 3                                    # not a degenerate single label
+    with pytest.raises(Exception):
+        F.DepthAdaptiveSuperpixel(w, h).Segmentation(dev(torch_cuda, bgr), dev(torch_cuda, pts_as_f32(pts)), 0.0, 0.0, 0.0, 1)

@@ -43,7 +43,7 @@ def run(cases=100, seed=1, dump=""):
     state = {}
     for case in range(a.cases):
         state.clear()
-        kind = ["k1", "k1", "k1", "k0", "mrf", "rgbf", "spdsr"][int(rng.integers(0, 7))]
+        kind = ["k1", "k1", "k1", "k0", "mrf", "rgbf", "spdsr", "dasp", "dasp"][int(rng.integers(0, 9))]
         w, h = int(rng.integers(1, 200)), int(rng.integers(1, 150))
         try:
             if kind == "k1":
@@ -95,6 +95,33 @@ def run(cases=100, seed=1, dump=""):
                 mrf.Process(dev(torch, depth), dev(torch, bgr))
                 assert_mrf_close(host(mrf.getFiltered_Device()), O.mrf_kernel(depth, bgr, win, cs, sm), "MRF")
                 desc = f"mrf {w}x{h} win {win} sig {cs}/{sm}"
+            elif kind == "dasp":
+                from gpu_util import ld_records, mean_records, pts_as_f32
+                w, h = int(rng.integers(40, 260)), int(rng.integers(30, 200))
+                rows, cols = int(rng.integers(2, max(3, h // 8))), int(rng.integers(2, max(3, w // 8)))
+                sig = [float(rng.choice([0.0, 10.0, 40.0, 100.0, 200.0])) for _ in range(3)]
+                if sum(sig) == 0.0:
+                    sig[1] = 40.0
+                it = int(rng.integers(1, 5))
+                bgr, depth = scene(w, h)
+                K = synth.intrinsics(w, h)
+                pts = O.p2r_depth(depth, K)
+                dsp = F.DepthAdaptiveSuperpixel(w, h)
+                try:
+                    dsp.SetParametor(rows, cols, K)
+                except KdeError:
+                    print(f"[{case}] dasp {w}x{h} grid {rows}x{cols}: geometry rejected (guard)")
+                    continue
+                dsp.Segmentation(dev(torch, bgr), dev(torch, pts_as_f32(pts)), *sig, it)
+                labels, ld, mean, centers = O.dasp_segmentation(bgr, pts, rows, cols, K, *sig, it)
+                assert np.array_equal(host(dsp.getLabelDevice()), labels), "DASP labels"
+                gl = ld_records(dsp.getLDDevice())
+                assert np.array_equal(gl["l"], ld["l"]) and np.array_equal(gl["d"], ld["d"]), "DASP (distance, label) records"
+                gm = mean_records(dsp.getMeanDataDevice())
+                for fld in ("r", "g", "b", "x", "y", "size"):
+                    assert np.array_equal(gm[fld], mean[fld]), f"DASP mean.{fld}"
+                assert np.array_equal(host(dsp.getCentersDevice()), pts_as_f32(centers), equal_nan=True), "DASP centres"
+                desc = f"dasp {w}x{h} grid {rows}x{cols} sig {sig} it {it}"
             elif kind == "spdsr":
                 from gpu_util import pts_as_f32
                 w, h = int(rng.integers(48, 200)), int(rng.integers(40, 150))
