@@ -404,6 +404,11 @@ __global__ __launch_bounds__(kThreads) void enhance_kernel(EnhDev a)
 // -------------------------------------------------------------------------------------------------
 constexpr uint32_t kMagic = 0x4B000000u, kOff = 1u << 18, kInvalidBias = 0xFF000000u;
 constexpr float kBiasF = 8388608.0f + 262144.0f;
+// Both tuned kernels form every weight at 2^24 times its value (added to the log2(S) table on the host): v_exp_f32
+// flushes results below 2^-126, which at this scale is the float32 underflow-to-zero point 2^-150 of the reference's
+// product S*cf*df, so weights the reference still holds as denormals keep full precision, weights it rounds to 0
+// vanish, and "denominator == 0" (EdgeRefinedSuperpixel.cu:196) falls where the reference's falls (see jbf_fast.hip).
+constexpr double kScaleLog2 = 24.0;
 constexpr int32_t kInvalidLabel = (int32_t)0x80000000;
 
 struct Enh7Dev {
@@ -912,9 +917,9 @@ int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bg
             d.t2_skip = t2 < 3.0e38 ? (float)t2 : 3.0e38f;
         }
         d.exp_zero = exp_zero;
-        auto lg = [&](int i, int j) {   // S == 0 -> factor skipped -> log2 = 0
+        auto lg = [&](int i, int j) {   // S == 0 -> factor skipped -> log2 = 0; + the 2^24 scale (kScaleLog2)
             const float sv = table_host[i * 7 + j];
-            return sv == 0.0f ? 0.0f : (float)std::log2((double)sv);
+            return (float)((sv == 0.0f ? 0.0 : std::log2((double)sv)) + kScaleLog2);
         };
         for (int i = 0; i < 7; i++)
             for (int u = 0; u < 7; u++) {   // unit -> (tap of p0, tap of p1): see enhance7_pk_kernel
@@ -968,8 +973,8 @@ int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bg
             d.t_skip = (float)(std::sqrt((double)val(lo)) * std::sqrt(log2e / (double)dden));
         }
         d.exp_zero = exp_zero;
-        for (int i = 0; i < 49; i++)   // S == 0 -> factor skipped -> log2 = 0
-            d.ls[i] = table_host[i] == 0.0f ? 0.0f : (float)std::log2((double)table_host[i]);
+        for (int i = 0; i < 49; i++)   // S == 0 -> factor skipped -> log2 = 0; + the 2^24 scale (kScaleLog2)
+            d.ls[i] = (float)((table_host[i] == 0.0f ? 0.0 : std::log2((double)table_host[i])) + kScaleLog2);
         // rank table: c_0 = ColorSigma, c_k = c_{k-1} * 0.3f (EdgeRefinedSuperpixel.cu:172-175 while a <= 0.3 c)
         float c = color_sigma;
         d.tinv[0] = 1.0f;    // rank 0 = only invalid taps so far: any positive scale keeps -1.7e38 * scale at -huge

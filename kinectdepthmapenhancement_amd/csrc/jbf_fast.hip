@@ -15,6 +15,12 @@
 //     on the ARGUMENT (integer colour distance / |d_q - avg|) against host-computed thresholds, so it does
 //     not depend on how small numbers are rounded by the exp hardware; in the packed kernels the decision is
 //     a {0,1} mask produced by the VOP3P clamp bit (no v_cmp / v_cndmask);
+//   * every weight is formed at 2^24 times its value (kScaleLog2 is folded into the log2(S) table on the host, so it
+//     costs nothing): v_exp_f32 flushes results below 2^-126, which at this scale is exactly the float32
+//     underflow-to-zero point 2^-150 of the reference's product S*cf*df -- weights the reference still represents
+//     (as denormals) are kept with full precision, weights it rounds to 0 vanish here too, and the two decisions
+//     "sum of weights > 0" / "denominator == 0" (JointBilateralFilter.cu:39,76) fall where the reference's fall.
+//     The scale cancels in both quotients;
 //   * each thread owns PX horizontally adjacent pixels and walks the window row by row from registers.
 // Depth + guide + |b|^2 tiles (with halo) are staged once per workgroup in LDS; the workgroup->tile map
 // keeps each XCD on a contiguous band of tiles so halos are shared in that XCD's L2.
@@ -27,6 +33,7 @@ constexpr uint32_t kMagic = 0x4B000000u;      // float 2^23
 constexpr uint32_t kOff = 1u << 18;           // keeps 2 a.b - |b|^2 + kOff positive (|b|^2 <= 195075 < 2^18)
 constexpr uint32_t kInvalidBias = 0xFF000000u; // as a float: -1.7e38; as an unsigned int: above every valid code
 constexpr float kBiasF = 8388608.0f + 262144.0f;
+constexpr double kScaleLog2 = 24.0;           // weights are summed at 2^24 scale (see the header comment)
 
 struct FastArgs {
     const float* depth;
@@ -607,7 +614,7 @@ int launch_jbf_fast(const JbfLaunch& l, int variant, const float* table_host, hi
     const int W = l.window, HALF = (W - 1) / 2;
     auto lg = [&](int i, int j) {
         const float sv = table_host[i * W + j];
-        return (sv == 0.0f) ? 0.0f : (float)std::log2((double)sv);   // S == 0 -> factor skipped
+        return (float)(((sv == 0.0f) ? 0.0 : std::log2((double)sv)) + kScaleLog2);   // S == 0 -> factor skipped
     };
     if (!kVariants[variant].packed) {
         for (int i = 0; i < W; i++)

@@ -146,9 +146,73 @@ static inline float color_diff3(const uint8_t* a, const uint8_t* b)
     return d0 * d0 + d1 * d1 + d2 * d2;
 }
 
+/* ---- the parity envelope (test infrastructure of the test infrastructure) -----------------------------
+ * K1 is discontinuous (Q1: a factor that underflowed to exactly 0 is not multiplied in) and, at small depth
+ * sigmas, ill-conditioned in its own first-pass average.  No float32 evaluation in another order can be held to
+ * 1e-4 against THIS float32 evaluation at such pixels, so the probe below says what any faithful evaluation
+ * may return there: the binary64 value of the same formula with the reference's decisions, re-evaluated with
+ *   - the first-pass average moved by +-eps (eps = the rounding a float32 sum of n_eff weights cannot avoid),
+ *   - the depth-factor underflow threshold (x = 150 ln 2) moved by +-1.5e-4 relative,
+ *   - the float32 underflow-to-zero point of a whole weight (2^-150) moved by +-5e-4 relative,
+ * the last two only where a tap actually sits inside such a band.  [lo, hi] spans the non-zero results (the
+ * float32 restatement's own value included); flags say whether 0 is one of the admissible results.
+ * The test asserts EVERY pixel: unflagged ones against the float32 value at 1e-4, flagged ones inside [lo, hi]. */
+#define OKDE_MAXTAPS (31 * 31)
+typedef struct {
+    int n;                       /* valid taps */
+    double d[OKDE_MAXTAPS];      /* depth of the tap */
+    double base[OKDE_MAXTAPS];   /* S * colour factor in binary64, decisions as the float32 code takes them */
+} jbf_taps;
+
+static const double kXZ = 103.97207708399179;      /* 150 ln 2: expf(-x) == 0 (round to nearest) for x beyond */
+static const double kUnder = 0x1p-150;              /* a float32 product at or below this rounds to 0 */
+
+/* both passes in binary64; returns the result (0 = "output is 0"), *band |= 1 when a tap sits in a decision band */
+static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double avg_rel, double thr_scale,
+                         double und_scale, int* band, double* n_eff)
+{
+    const double U = kUnder * und_scale;
+    double wa = 0.0, wt = 0.0, wt2 = 0.0;
+    for (int k = 0; k < t->n; k++) {
+        double f = t->base[k];
+        if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
+        if (f <= U) f = 0.0;
+        wa += t->d[k] * f;
+        wt += f;
+        wt2 += f * f;
+    }
+    if (!(wt > 0.0)) return 0.0;
+    if (n_eff) *n_eff = wt * wt / wt2;
+    wa = wa / wt * (1.0 + avg_rel);
+    double nu = 0.0, de = 0.0;
+    for (int k = 0; k < t->n; k++) {
+        double f = t->base[k];
+        if (f <= U) continue;
+        if (depth_on) {
+            const double xd = (t->d[k] - wa) * (t->d[k] - wa) / dden;
+            if (fabs(xd / kXZ - 1.0) <= 1.5e-4) *band |= 1;
+            if (xd < kXZ * thr_scale) f *= exp(-xd);
+            if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
+            if (f <= U) continue;
+        }
+        nu += t->d[k] * f;
+        de += f;
+    }
+    return de > 0.0 ? nu / de : 0.0;
+}
+
+typedef struct { double lo, hi; int zero, nonzero; } env_acc;
+static void env_add(env_acc* e, double r)
+{
+    if (r == 0.0) { e->zero = 1; return; }
+    if (!e->nonzero || r < e->lo) e->lo = r;
+    if (!e->nonzero || r > e->hi) e->hi = r;
+    e->nonzero = 1;
+}
+
 void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* guide,
                      const float* spatial, int window_size, float color_sigma, float depth_sigma,
-                     float* filtered, uint8_t* ill)
+                     float* filtered, const okde_env* env)
 {
     const int hw = window_size / 2;
 #pragma omp parallel for schedule(static) num_threads(g_threads)
@@ -177,7 +241,6 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                 }
             }
             float out = 0.0f;
-            uint8_t flag = 0;
             if (weight > 0.0f) {
                 w_average /= weight;
                 /* filtering — .cu:43-78 */
@@ -195,14 +258,8 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                             float dd = dq - w_average;
                             float depth_diff = dd * dd;
                             float depth_filter = 0.0f; /* Q3: uninitialised in the reference */
-                            if (depth_sigma != 0.0f) {
-                                float xarg = depth_diff / (2.0f * (depth_sigma * depth_sigma));
-                                depth_filter = expf(-xarg);
-                                /* the factor jumps from ~1e-45 to "skipped" (= 1) where expf underflows
-                                 * (x = 150 ln 2): a tap this close to the jump makes the pixel
-                                 * discontinuous in the last ulps of w_average */
-                                if (fabsf(xarg - 103.972077f) <= 103.972077f * 1e-4f) flag |= 2;
-                            }
+                            if (depth_sigma != 0.0f)
+                                depth_filter = expf(-(depth_diff / (2.0f * (depth_sigma * depth_sigma))));
                             float filter = 1.0f;
                             float s = spatial[(i + hw) * window_size + (j + hw)];
                             if (s != 0.0f) filter *= s;
@@ -215,81 +272,70 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                 }
                 if (denominator == 0.0f) out = 0.0f;
                 else out = numerator / denominator;
-                if (denominator < 1e-30f) flag |= 1;
             }
             filtered[(size_t)y * width + x] = out;
-            if (ill) {
-                /* conditioning probe: the same two passes in binary64 (same skip decisions up to the
-                 * threshold band flagged above).  Where the float32 result of the restatement itself
-                 * moves by more than 2e-5 against it, the pixel amplifies 1e-7 roundings by > 200x and
-                 * no float32 implementation can be held to 1e-4 there. */
-                if (weight > 0.0f && out != 0.0f) {
-                    const double cden = 2.0 * (double)color_sigma * (double)color_sigma;
-                    const double dden = 2.0 * (double)depth_sigma * (double)depth_sigma;
-                    const double xz = 103.97207708399179;
-                    double wa = 0.0, wt = 0.0, wt2 = 0.0;
-                    for (int i = -hw; i <= hw; i++)
-                        for (int j = -hw; j <= hw; j++) {
-                            int xj = x + j, yi = y + i;
-                            if (xj >= 0 && xj < width && yi >= 0 && yi < height &&
-                                depth[(size_t)yi * width + xj] > 50.0f) {
-                                double cdv = (double)color_diff3(cc, guide + ((size_t)yi * width + xj) * 3);
-                                double f = 1.0;
-                                float sv = spatial[(i + hw) * window_size + (j + hw)];
-                                if (sv != 0.0f) f *= (double)sv;
-                                if (color_sigma != 0.0f && cdv / cden < xz) f *= exp(-cdv / cden);
-                                wa += (double)depth[(size_t)yi * width + xj] * f;
-                                wt += f;
-                                wt2 += f * f;
-                            }
-                        }
-                    wa /= wt;
-                    /* second pass at the binary64 average and at the average moved by +-eps: a float32 implementation
-                     * cannot know the first-pass average better than a few ulps plus the rounding of its sum over the
-                     * taps that carry weight.  Where such a move changes the result by more than
-                     * 1e-4 (small depth sigma against large depths), or flips the skip decision of a tap (the Q1 jump),
-                     * the pixel amplifies that rounding beyond the tolerance whatever the evaluation order. */
-                    /* rounding of a float32 sum grows with the number of taps that carry weight: the participation
-                     * ratio (sum w)^2 / sum w^2; measured 25 ulps at 128 equal weights -> 2.5 sqrt(n_eff) */
-                    const double n_eff = wt2 > 0.0 ? wt * wt / wt2 : 1.0;
-                    const double eps_avg = (4.0 + 2.5 * sqrt(n_eff)) * 1.1920928955078125e-7;
-                    double res[3] = {0.0, 0.0, 0.0};
-                    double nu = 0.0, de = 0.0;
-                    for (int pv = 0; pv < 3; pv++) {
-                        const double wap = wa * (1.0 + (double)(pv == 0 ? 0 : (pv == 1 ? 1 : -1)) * eps_avg);
-                        double n2 = 0.0, d2 = 0.0;
-                        for (int i = -hw; i <= hw; i++)
-                            for (int j = -hw; j <= hw; j++) {
-                                int xj = x + j, yi = y + i;
-                                if (xj >= 0 && xj < width && yi >= 0 && yi < height &&
-                                    depth[(size_t)yi * width + xj] > 50.0f) {
-                                    double dq = (double)depth[(size_t)yi * width + xj];
-                                    double cdv = (double)color_diff3(cc, guide + ((size_t)yi * width + xj) * 3);
-                                    double f = 1.0;
-                                    float sv = spatial[(i + hw) * window_size + (j + hw)];
-                                    if (sv != 0.0f) f *= (double)sv;
-                                    if (color_sigma != 0.0f && cdv / cden < xz) f *= exp(-cdv / cden);
-                                    double xd = (dq - wap) * (dq - wap) / dden;
-                                    if (depth_sigma != 0.0f && xd < xz) f *= exp(-xd);
-                                    if (pv != 0 && depth_sigma != 0.0f) {
-                                        double x0d = (dq - wa) * (dq - wa) / dden;
-                                        if ((xd < xz) != (x0d < xz)) flag |= 2;
-                                    }
-                                    n2 += dq * f;
-                                    d2 += f;
-                                }
-                            }
-                        res[pv] = d2 > 0.0 ? n2 / d2 : 0.0;
-                        if (pv == 0) {
-                            nu = n2;
-                            de = d2;
+            if (env && env->flags) {
+                const size_t p = (size_t)y * width + x;
+                uint8_t flag = 0;
+                env_acc e = {0.0, 0.0, 0, 0};
+                if (out != out) {               /* NaN in (inf depth): nothing to bracket, NaN must coincide */
+                    env->flags[p] = 0;
+                    if (env->lo) env->lo[p] = env->hi[p] = (double)out;
+                    continue;
+                }
+                jbf_taps t;
+                t.n = 0;
+                const double cden = 2.0 * (double)color_sigma * (double)color_sigma;
+                const double dden = 2.0 * (double)depth_sigma * (double)depth_sigma;
+                for (int i = -hw; i <= hw; i++)
+                    for (int j = -hw; j <= hw; j++) {
+                        int xj = x + j, yi = y + i;
+                        if (xj >= 0 && xj < width && yi >= 0 && yi < height &&
+                            depth[(size_t)yi * width + xj] > 50.0f && t.n < OKDE_MAXTAPS) {
+                            float color_diff = color_diff3(cc, guide + ((size_t)yi * width + xj) * 3);
+                            double f = 1.0;
+                            float sv = spatial[(i + hw) * window_size + (j + hw)];
+                            if (sv != 0.0f) f *= (double)sv;
+                            /* the colour factor is skipped exactly when the float32 code skips it */
+                            if (color_sigma != 0.0f && expf(-color_diff / (2 * (color_sigma * color_sigma))) != 0.0f)
+                                f *= exp(-(double)color_diff / cden);
+                            t.d[t.n] = (double)depth[(size_t)yi * width + xj];
+                            t.base[t.n] = f;
+                            t.n++;
                         }
                     }
-                    if (de > 0.0 && (fabs(res[1] - res[0]) > 1e-4 * fabs(res[0]) || fabs(res[2] - res[0]) > 1e-4 * fabs(res[0])))
-                        flag |= 4;
-                    if (de > 0.0 && fabs((double)out - nu / de) > 2e-5 * fabs(nu / de)) flag |= 4;
+                int band = 0;
+                double n_eff = 1.0;
+                const double r0 = jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &band, &n_eff);
+                /* rounding of a float32 sum grows with the number of taps that carry weight: the participation
+                 * ratio (sum w)^2 / sum w^2; measured 25 ulps at 128 equal weights -> 2.5 sqrt(n_eff) */
+                const double eps_avg = (4.0 + 2.5 * sqrt(n_eff)) * 1.1920928955078125e-7;
+                env_add(&e, r0);
+                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, eps_avg, 1.0, 1.0, &band, NULL));
+                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, -eps_avg, 1.0, 1.0, &band, NULL));
+                if (band) {
+                    flag |= 2;
+                    for (int a = -1; a <= 1; a++)
+                        for (int b = -1; b <= 1; b++)
+                            for (int c = -1; c <= 1; c++) {
+                                int dummy = 0;
+                                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, a * eps_avg, 1.0 + b * 1.5e-4,
+                                                       1.0 + c * 5e-4, &dummy, NULL));
+                            }
                 }
-                ill[(size_t)y * width + x] = flag;
+                env_add(&e, (double)out);
+                if (e.nonzero) {
+                    const double mid = r0 != 0.0 ? r0 : e.lo;
+                    if (e.hi - e.lo > 2e-5 * fabs(mid)) flag |= 4;
+                } else {
+                    e.lo = e.hi = 0.0;
+                }
+                if (e.zero) flag |= 8;
+                env->flags[p] = flag;
+                if (env->lo) {
+                    env->lo[p] = e.lo;
+                    env->hi[p] = e.hi;
+                }
             }
         }
     }
@@ -299,7 +345,7 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
 void okde_jbf_process(int width, int height, const float* depth, const uint8_t* bgr,
                       int window, float spatial_sigma, float color_sigma, float depth_sigma,
                       int presmooth_ksize, float presmooth_sigma_color, float presmooth_sigma_spatial,
-                      uint8_t* smooth_out, float* filtered, uint8_t* ill)
+                      uint8_t* smooth_out, float* filtered, const okde_env* env)
 {
     float* table = (float*)malloc(sizeof(float) * (size_t)window * window);
     okde_spatial_table(window, spatial_sigma, table);
@@ -314,7 +360,7 @@ void okde_jbf_process(int width, int height, const float* depth, const uint8_t* 
     } else if (smooth_out) {
         memcpy(smooth_out, bgr, (size_t)width * height * 3);
     }
-    okde_jbf_kernel(width, height, depth, guide, table, window, color_sigma, depth_sigma, filtered, ill);
+    okde_jbf_kernel(width, height, depth, guide, table, window, color_sigma, depth_sigma, filtered, env);
     free(tmp);
     free(table);
 }
@@ -819,9 +865,64 @@ void okde_ers_edge_refining(int width, int height, const int32_t* color_labels,
 /* ------------------------------------------------------------------------------------------
  * K10 — depthmap_enhancement, EdgeRefinedSuperpixel.cu:104-205 (D3: separate output buffer)
  * ---------------------------------------------------------------------------------------- */
-static uint8_t* g_ers_flag_sink = NULL;
+static const okde_env* g_ers_env_sink = NULL;
 
-void okde_ers_set_flag_sink(uint8_t* sink) { g_ers_flag_sink = sink; }
+void okde_ers_set_env_sink(const okde_env* sink) { g_ers_env_sink = sink; }
+
+/* taps of one K10 window for the binary64 envelope (see okde_env): every valid in-image tap in raster order */
+typedef struct {
+    int n;
+    double d[OKDE_MAXTAPS];
+    double s[OKDE_MAXTAPS];       /* spatial factor (1 where the table entry is 0: factor skipped) */
+    float cd[OKDE_MAXTAPS];       /* colour distance */
+    uint8_t same[OKDE_MAXTAPS];   /* same refined label as the centre */
+} ers_taps;
+
+/* the three passes in binary64 with the float32 code's decisions; a = adaptive sigma as the float32 code formed it.
+ * Returns the result (0 = "output is 0", NaN = the Q6 quirk); *band |= 1 when a tap sits in a decision band. */
+static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, int depth_on, float a, double avg_rel,
+                         double thr_scale, double und_scale, int* band, double* n_eff)
+{
+    const double U = kUnder * und_scale;
+    double wa = 0.0, wt = 0.0, wt2 = 0.0;
+    for (int k = 0; k < t->n; k++) {
+        if (!t->same[k]) continue;
+        double f = t->s[k];
+        if (color_sigma_in != 0.0f && expf(-t->cd[k] / (2 * (color_sigma_in * color_sigma_in))) != 0.0f)
+            f *= exp(-(double)t->cd[k] / (2.0 * (double)color_sigma_in * (double)color_sigma_in));
+        if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
+        if (f <= U) f = 0.0;
+        wa += t->d[k] * f;
+        wt += f;
+        wt2 += f * f;
+    }
+    if (!(wt > 0.0)) return 0.0;
+    if (n_eff) *n_eff = wt * wt / wt2;
+    wa = wa / wt * (1.0 + avg_rel);
+    float cs = color_sigma_in;
+    double nu = 0.0, de = 0.0;
+    for (int k = 0; k < t->n; k++) {
+        double f = t->s[k];
+        if (cs != 0.0f) {
+            if (a > cs * 0.3f) cs = a;
+            else cs *= 0.3f;
+            const float cf32 = expf(-t->cd[k] / (2 * (cs * cs)));       /* decision (and NaN) as the float32 code */
+            if (cf32 != cf32) f = (double)cf32;
+            else if (cf32 != 0.0f) f *= exp(-(double)t->cd[k] / (2.0 * (double)(cs * cs)));
+        }
+        if (depth_on) {
+            const double xd = (t->d[k] - wa) * (t->d[k] - wa) / dden;
+            if (fabs(xd / kXZ - 1.0) <= 1.5e-4) *band |= 1;
+            if (xd < kXZ * thr_scale) f *= exp(-xd);
+        }
+        if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
+        if (f <= U) continue;            /* NaN fails the test and is summed in, as in float32 */
+        nu += t->d[k] * f;
+        de += f;
+    }
+    if (de != de || nu != nu) return NAN;
+    return de > 0.0 ? nu / de : 0.0;
+}
 
 void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr,
                       const int32_t* refined_labels, const float* spatial, int window_size,
@@ -855,12 +956,11 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                     }
                 }
             float result = 0.0f;
-            uint8_t near_jump = 0;
+            float adaptive = 0.0f, deviation = 0.0f;
             if (weight > 0.0f) {
                 w_average /= weight;
                 /* deviation — .cu:143-156 */
                 int count = 0;
-                float deviation = 0.0f;
                 for (int i = -hw; i <= hw; i++)
                     for (int j = -hw; j <= hw; j++) {
                         int xj = x + j, yi = y + i;
@@ -873,11 +973,6 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                         }
                     }
                 if (count != 0) deviation /= (float)count;
-                /* Q6 is a discontinuity as well: a deviation of exactly 0 (adaptive sigma 0 -> 0/0 = NaN once the
-                 * decayed sigma has underflowed) and a deviation of one rounding error (finite result) are told apart
-                 * only by how (sum d*w)/(sum w) happens to round -- a single same-label tap is the extreme case.
-                 * Deviations within a few ulps of the average are flagged. */
-                if (deviation <= 16.0f * 1.1920929e-7f * fabsf(w_average)) near_jump |= 4;
                 /* filtering — .cu:158-200; the label test is commented out in the reference */
                 float numerator = 0.0f, denominator = 0.0f;
                 for (int i = -hw; i <= hw; i++)
@@ -892,6 +987,7 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                                     /* .cu:171: 5.0 is a double literal; pow(float,float) is float */
                                     float adaptive_sigma =
                                         (float)(5.0 * (double)deviation / (double)(w_average * w_average));
+                                    adaptive = adaptive_sigma;
                                     if (adaptive_sigma > color_sigma * 0.3f) color_sigma = adaptive_sigma;
                                     else color_sigma *= 0.3f;
                                     color_filter = expf(-color_diff / (2 * (color_sigma * color_sigma)));
@@ -899,12 +995,8 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                                 float dd = rd[q] - w_average;
                                 float depth_diff = dd * dd;
                                 float depth_filter = 0.0f; /* Q3 */
-                                if (depth_sigma != 0.0f) {
-                                    float xarg = depth_diff / (2.0f * (depth_sigma * depth_sigma));
-                                    depth_filter = expf(-xarg);
-                                    /* same discontinuity as in K1 (Q1): flag taps sitting on the underflow jump */
-                                    if (fabsf(xarg - 103.972077f) <= 103.972077f * 1e-4f) near_jump = 1;
-                                }
+                                if (depth_sigma != 0.0f)
+                                    depth_filter = expf(-(depth_diff / (2.0f * (depth_sigma * depth_sigma))));
                                 float filter = 1.0f;
                                 float s = spatial[(i + hw) * window_size + (j + hw)];
                                 if (s != 0.0f) filter *= s;
@@ -917,12 +1009,81 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                     }
                 if (denominator == 0.0f) result = 0.0f;
                 else result = numerator / denominator;
-                /* every surviving weight is denormal-scale (a window straddling a depth step several DepthSigma
-                 * high): the ratio of two denormal sums has a few bits, in any float32 evaluation -- as in K1 */
-                if (denominator < 1e-30f) near_jump |= 4;
             }
             out[p] = result;
-            if (g_ers_flag_sink) g_ers_flag_sink[p] = (uint8_t)(((near_jump & 1) ? 2 : 0) | ((near_jump & 4) ? 1 : 0));
+            const okde_env* env = g_ers_env_sink;
+            if (env && env->flags) {
+                uint8_t flag = 0;
+                env_acc e = {0.0, 0.0, 0, 0};
+                int nan_ok = 0;
+                ers_taps t;
+                t.n = 0;
+                for (int i = -hw; i <= hw; i++)
+                    for (int j = -hw; j <= hw; j++) {
+                        int xj = x + j, yi = y + i;
+                        if (xj >= 0 && xj < width && yi >= 0 && yi < height && t.n < OKDE_MAXTAPS) {
+                            const size_t q = (size_t)yi * width + xj;
+                            if (rd[q] > 50.0f) {
+                                const float sv = spatial[(i + hw) * window_size + (j + hw)];
+                                t.d[t.n] = (double)rd[q];
+                                t.s[t.n] = sv != 0.0f ? (double)sv : 1.0;
+                                t.cd[t.n] = color_diff3(cc, bgr + q * 3);
+                                t.same[t.n] = refined_labels[p] == refined_labels[q];
+                                t.n++;
+                            }
+                        }
+                    }
+                const double dden = 2.0 * (double)depth_sigma * (double)depth_sigma;
+                const int don = depth_sigma != 0.0f;
+                /* the adaptive sigma only matters through "is it exactly 0" (Q6: 0/0 = NaN once the decayed sigma has
+                 * underflowed): a deviation of exactly 0 and a deviation of one rounding error are told apart only by
+                 * how (sum d*w)/(sum w) happens to round.  Deviations within a few ulps of the average get both. */
+                float alt[2] = {adaptive, adaptive};
+                int nalt = 1;
+                if (weight > 0.0f && deviation <= 16.0f * 1.1920929e-7f * fabsf(w_average)) {
+                    alt[1] = adaptive == 0.0f ? (float)(5.0 * 1.1920929e-7 / (double)fabsf(w_average)) : 0.0f;
+                    nalt = 2;
+                    flag |= 2;
+                }
+                int band = 0;
+                double n_eff = 1.0;
+                const double r0 = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band, &n_eff);
+                const double eps_avg = (4.0 + 2.5 * sqrt(n_eff)) * 1.1920928955078125e-7;
+                for (int v = 0; v < nalt; v++)
+                    for (int a = -1; a <= 1; a++) {
+                        const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg, 1.0, 1.0, &band, NULL);
+                        if (r != r) nan_ok = 1;
+                        else env_add(&e, r);
+                    }
+                if (band) {
+                    flag |= 2;
+                    for (int v = 0; v < nalt; v++)
+                        for (int a = -1; a <= 1; a++)
+                            for (int b = -1; b <= 1; b++)
+                                for (int c = -1; c <= 1; c++) {
+                                    int dummy = 0;
+                                    const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg,
+                                                                1.0 + b * 1.5e-4, 1.0 + c * 5e-4, &dummy, NULL);
+                                    if (r != r) nan_ok = 1;
+                                    else env_add(&e, r);
+                                }
+                }
+                if (result != result) nan_ok = 1;
+                else env_add(&e, (double)result);
+                if (e.nonzero) {
+                    const double mid = (r0 == r0 && r0 != 0.0) ? r0 : e.lo;
+                    if (e.hi - e.lo > 2e-5 * fabs(mid)) flag |= 4;
+                } else {
+                    e.lo = e.hi = 0.0;
+                }
+                if (e.zero) flag |= 8;
+                if (nan_ok) flag |= 16;
+                env->flags[p] = flag;
+                if (env->lo) {
+                    env->lo[p] = e.lo;
+                    env->hi[p] = e.hi;
+                }
+            }
         }
     }
 }

@@ -46,23 +46,38 @@ void okde_cv_bilateral_8uc3(const uint8_t* src, int width, int height, size_t sr
                             int kernel_size, float sigma_color, float sigma_spatial,
                             uint8_t* dst, size_t dst_step);
 
-/* K1: joint_bilateral_filtering, JointBilateralFilter/JointBilateralFilter.cu:4-83.
- * ill (optional, may be NULL): per-pixel flags marking outputs that are not well defined at the
- * 1e-4 level: bit 0 = final denominator < 1e-30 (every surviving weight is denormal-scale);
- * bit 1 = some tap's depth term sits within 1e-4 (relative) of the expf-underflow point, where the
- * reference's "factor == 0 -> skipped" rule (Q1) makes the output discontinuous in w_average;
- * bit 2 = the float32 result differs from a binary64 evaluation of the same formula by > 2e-5
- * (the pixel amplifies last-ulp roundings of w_average by more than 200x). */
+/* The parity envelope filled by okde_jbf_kernel / okde_ers_enhance on request (all three arrays W*H, lo/hi optional).
+ * K1 and K10 are discontinuous (Q1: "a factor that underflowed to exactly 0 is not multiplied in"; Q6) and can be
+ * ill-conditioned in their own first-pass average, so for every pixel the oracle also says what ANY faithful
+ * evaluation may return: [lo, hi] spans the binary64 values of the same formula with the first-pass average moved by
+ * the rounding a float32 sum cannot avoid and -- where a tap sits within 1.5e-4 of such a decision -- with the
+ * decision taken either way; the float32 restatement's own value is included.  flags:
+ *   bit 1 (2)  a tap sits on a Q1 decision (depth-factor underflow at x = 150 ln 2, or a whole weight at the
+ *              float32 underflow-to-zero point 2^-150): both outcomes are in [lo, hi]
+ *   bit 2 (4)  [lo, hi] is wider than 2e-5 relative (rounding of the average amplified, or the float32 value itself
+ *              is denormal-quantisation noise): the pixel is compared with the envelope instead of the float32 value
+ *   bit 3 (8)  0 is one of the admissible results (lo = hi = 0 when it is the only one)
+ *   bit 4 (16) NaN is one of the admissible results (K10's 0/0 quirk Q6 next to a deviation of one rounding error)
+ * (bit 0, "denominator < 1e-30", of round 1 is retired: the HIP kernels now sum at 2^24 scale and keep such weights.)
+ * Pixels with flags & 6 == 0 are held to 1e-4 against the float32 value; the others must lie inside [lo, hi]
+ * (or be 0 / NaN where the flags admit it).  No pixel is excluded from the comparison. */
+typedef struct {
+    uint8_t* flags;
+    double* lo;
+    double* hi;
+} okde_env;
+
+/* K1: joint_bilateral_filtering, JointBilateralFilter/JointBilateralFilter.cu:4-83.  env may be NULL. */
 void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* guide_bgr,
                      const float* spatial, int window, float color_sigma, float depth_sigma,
-                     float* filtered, uint8_t* ill);
+                     float* filtered, const okde_env* env);
 
 /* JointBilateralFilter::Process, JointBilateralFilter.cu:283-290 (K0 then K1).
  * presmooth_ksize <= -1000 disables the pre-smoothing (guide = colour). */
 void okde_jbf_process(int width, int height, const float* depth, const uint8_t* bgr,
                       int window, float spatial_sigma, float color_sigma, float depth_sigma,
                       int presmooth_ksize, float presmooth_sigma_color, float presmooth_sigma_spatial,
-                      uint8_t* smooth_out /* W*H*3 */, float* filtered, uint8_t* ill);
+                      uint8_t* smooth_out /* W*H*3 */, float* filtered, const okde_env* env);
 
 /* MarkovRandomField/MarkovRandomField.cu:4-40 (next-row f1) */
 void okde_mrf_kernel(int width, int height, const float* depth, const uint8_t* bgr,
@@ -112,9 +127,9 @@ void okde_ers_edge_refining(int width, int height, const int32_t* color_labels,
 void okde_ers_enhance(int width, int height, const float* refined_depth_in, const uint8_t* bgr,
                       const int32_t* refined_labels, const float* spatial, int window,
                       float color_sigma, float depth_sigma, float* refined_depth_out);
-/* optional W*H byte map that okde_ers_enhance fills with 2 where a tap's depth term sits within 1e-4 of the
- * expf-underflow jump (output discontinuous there, see okde_jbf_kernel); NULL switches it off */
-void okde_ers_set_flag_sink(uint8_t* sink);
+/* optional envelope that okde_ers_enhance fills (see okde_env); NULL switches it off.  A sink rather than an
+ * argument because the kernel runs deep inside okde_rgbf_process / okde_spdsr_head. */
+void okde_ers_set_env_sink(const okde_env* sink);
 void okde_ers_process(int width, int height, const int32_t* color_labels, const int32_t* depth_labels,
                       const float* depth, const uint8_t* bgr,
                       int32_t* refined_labels, float* refined_depth);

@@ -58,6 +58,42 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+class _CEnv(C.Structure):
+    _fields_ = [("flags", C.c_void_p), ("lo", C.c_void_p), ("hi", C.c_void_p)]
+
+
+class Env:
+    """The parity envelope of kde_oracle.h (okde_env): per pixel, flags and the interval [lo, hi] of values a faithful
+    evaluation may return.  BAND / COND pixels (`flagged`) are compared with the interval, all others with the float32
+    value; ZERO_OK / NAN_OK say whether 0 / NaN are admissible as well."""
+    BAND, COND, ZERO_OK, NAN_OK = 2, 4, 8, 16
+
+    def __init__(self, shape=None, flags=None, lo=None, hi=None):
+        if flags is None:
+            flags, lo, hi = np.zeros(shape, np.uint8), np.zeros(shape, np.float64), np.zeros(shape, np.float64)
+        self.flags = np.ascontiguousarray(flags, np.uint8)
+        self.lo = np.ascontiguousarray(lo, np.float64)
+        self.hi = np.ascontiguousarray(hi, np.float64)
+        self._c = _CEnv(self.flags.ctypes.data, self.lo.ctypes.data, self.hi.ctypes.data)
+
+    def ref(self):
+        return C.byref(self._c)
+
+    @property
+    def flagged(self):
+        return (self.flags & (self.BAND | self.COND)) != 0
+
+    def crop(self, ys, xs):
+        return Env(flags=self.flags[ys, xs], lo=self.lo[ys, xs], hi=self.hi[ys, xs])
+
+    def to_dict(self, prefix):
+        return {prefix + "_flags": self.flags, prefix + "_lo": self.lo, prefix + "_hi": self.hi}
+
+    @staticmethod
+    def from_dict(g, prefix):
+        return Env(flags=g[prefix + "_flags"], lo=g[prefix + "_lo"], hi=g[prefix + "_hi"])
+
+
 def set_threads(n: int) -> int:
     return lib().okde_set_threads(int(n))
 
@@ -88,10 +124,10 @@ def jbf_kernel(depth, guide, window=5, spatial_sigma=70.0, color_sigma=50.0, dep
     h, w = depth.shape
     tab = spatial_table(window, spatial_sigma)
     out = np.empty((h, w), np.float32)
-    ill = np.zeros((h, w), np.uint8) if return_ill else None
+    env = Env((h, w)) if return_ill else None          # the envelope probe only runs on request
     lib().okde_jbf_kernel(w, h, _p(depth), _p(guide), _p(tab), window, C.c_float(color_sigma),
-                          C.c_float(depth_sigma), _p(out), _p(ill) if return_ill else None)
-    return (out, ill) if return_ill else out
+                          C.c_float(depth_sigma), _p(out), env.ref() if return_ill else None)
+    return (out, env) if return_ill else out
 
 
 def jbf_process(depth, bgr, window=5, spatial_sigma=70.0, color_sigma=50.0, depth_sigma=20.0,
@@ -101,12 +137,12 @@ def jbf_process(depth, bgr, window=5, spatial_sigma=70.0, color_sigma=50.0, dept
     h, w = depth.shape
     out = np.empty((h, w), np.float32)
     smooth = np.empty((h, w, 3), np.uint8)
-    ill = np.zeros((h, w), np.uint8) if return_all else None    # the conditioning probe only runs on request
+    env = Env((h, w)) if return_all else None    # the envelope probe only runs on request
     ks, sc, ss = presmooth if presmooth is not None else (-100000, 0.0, 0.0)
     lib().okde_jbf_process(w, h, _p(depth), _p(bgr), window, C.c_float(spatial_sigma),
                            C.c_float(color_sigma), C.c_float(depth_sigma), ks, C.c_float(sc),
-                           C.c_float(ss), _p(smooth), _p(out), _p(ill) if return_all else None)
-    return (out, smooth, ill) if return_all else out
+                           C.c_float(ss), _p(smooth), _p(out), env.ref() if return_all else None)
+    return (out, smooth, env) if return_all else out
 
 
 def mrf_kernel(depth, bgr, window=5, color_sigma=50.0, smooth_sigma=150.0):
@@ -265,17 +301,17 @@ def ers_edge_refining(color_labels, depth_labels, depth, window=7):
 
 
 class ers_flags:
-    """context manager: collects okde_ers_enhance's discontinuity flags for every call made inside it"""
+    """context manager: collects okde_ers_enhance's parity envelope (Env) for the call made inside it"""
 
     def __init__(self, shape):
-        self.flags = np.zeros(shape, np.uint8)
+        self.env = Env(shape)
 
     def __enter__(self):
-        lib().okde_ers_set_flag_sink(_p(self.flags))
-        return self.flags
+        lib().okde_ers_set_env_sink(self.env.ref())
+        return self.env
 
     def __exit__(self, *exc):
-        lib().okde_ers_set_flag_sink(None)
+        lib().okde_ers_set_env_sink(None)
         return False
 
 

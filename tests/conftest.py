@@ -61,28 +61,66 @@ def torch_cuda():
     return torch
 
 
-def assert_depth_close(got, ref, rtol=1e-4, ill=None, max_bad=0, what="depth"):
-    """HIP vs oracle bar for float depth maps: identical zero / non-zero mask and <= rtol relative
-    error on non-zero outputs (NaNs must coincide).  Pixels the oracle flags ill-conditioned
-    (every surviving weight denormal-scale) are excluded and counted."""
+PARITY_LOG = []     # one line per assert_depth_close call with an envelope; printed in the terminal summary
+
+
+def pytest_terminal_summary(terminalreporter):
+    if PARITY_LOG:
+        terminalreporter.write_sep("-", "parity classes (no pixel is excluded; flagged pixels are held to the oracle's envelope)")
+        for line in PARITY_LOG:
+            terminalreporter.write_line(line)
+
+
+def assert_depth_close(got, ref, rtol=1e-4, ill=None, max_bad=0, what="depth", max_flagged=None):
+    """HIP vs oracle bar for float depth maps.  EVERY pixel is checked:
+      * pixels the oracle's envelope does not flag (and all pixels when no envelope is given): identical zero / NaN
+        mask and <= rtol relative error against the float32 restatement;
+      * flagged pixels (oracle.Env: a tap on a Q1 decision, or the pixel amplifies the rounding of its own first-pass
+        average beyond 2e-5): the value must lie inside the envelope [lo, hi] of binary64 evaluations of the same
+        formula (widened by rtol), or be 0 / NaN where the envelope admits that.
+    Returns the max relative error on unflagged pixels; per-class counts and the max error on flagged pixels are
+    logged (PARITY_LOG) and `max_flagged` bounds the flagged fraction."""
     got = np.asarray(got, np.float32)
     ref = np.asarray(ref, np.float32)
     assert got.shape == ref.shape
-    keep = np.ones(ref.shape, bool) if ill is None else ~np.asarray(ill, bool)
+    if ill is not None and not hasattr(ill, "flagged"):
+        raise TypeError("assert_depth_close needs an oracle.Env (flags + envelope), not a bare flag map")
+    flagged = np.zeros(ref.shape, bool) if ill is None else ill.flagged.reshape(ref.shape)
     nan_ref, nan_got = np.isnan(ref), np.isnan(got)
-    bad_nan = (nan_ref != nan_got) & keep
-    zero_mismatch = ((ref == 0) != (got == 0)) & keep & ~nan_ref & ~nan_got
-    fin = keep & ~nan_ref & ~nan_got & (ref != 0) & (got != 0)
-    rel = np.zeros(ref.shape, np.float64)
-    rel[fin] = np.abs(got[fin].astype(np.float64) - ref[fin]) / np.abs(ref[fin])
-    bad = bad_nan | zero_mismatch | (rel > rtol)
+    g64, r64 = got.astype(np.float64), ref.astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.where((ref != 0) & ~nan_ref & ~nan_got, np.abs(g64 - r64) / np.abs(r64), 0.0)
+    # unflagged: strict
+    strict = ~flagged
+    bad_nan = strict & (nan_ref != nan_got)
+    bad_zero = strict & ~nan_ref & ~nan_got & ((ref == 0) != (got == 0))
+    bad_rel = strict & (rel > rtol)
+    bad = bad_nan | bad_zero | bad_rel
+    bad_env = np.zeros(ref.shape, bool)
+    if ill is not None and flagged.any():
+        fl = ill.flags.reshape(ref.shape)
+        lo, hi = ill.lo.reshape(ref.shape), ill.hi.reshape(ref.shape)
+        zero_ok = ((fl & 8) != 0) | (ref == 0)
+        nan_ok = ((fl & 16) != 0) | nan_ref
+        inside = (hi > 0) & (g64 >= lo * (1 - rtol)) & (g64 <= hi * (1 + rtol))
+        ok = np.where(nan_got, nan_ok, np.where(got == 0, zero_ok, inside))
+        bad_env = flagged & ~ok
+        bad |= bad_env
+        nfl = int(flagged.sum())
+        frac = nfl / flagged.size
+        PARITY_LOG.append(f"{what}: {flagged.size} px, flagged {nfl} ({frac:.2e}: band {int(((fl & 2) != 0).sum())}, "
+                          f"cond {int(((fl & 4) != 0).sum())}), max rel err unflagged {rel[strict].max() if strict.any() else 0:.2e}, "
+                          f"flagged vs float32 value {rel[flagged].max():.2e}, outside envelope {int(bad_env.sum())}")
+        if max_flagged is not None:
+            assert frac <= max_flagged, f"{what}: {frac:.3e} of the pixels flagged (> {max_flagged})"
     nbad = int(bad.sum())
     if nbad > max_bad:
         idx = np.argwhere(bad)[:10]
         detail = [(tuple(i), float(got[tuple(i)]), float(ref[tuple(i)])) for i in idx]
-        raise AssertionError(f"{what}: {nbad} pixels off (nan {int(bad_nan.sum())}, zero-mask "
-                             f"{int(zero_mismatch.sum())}, max rel {rel.max():.3e}); first: {detail}")
-    return float(rel.max())
+        raise AssertionError(f"{what}: {nbad} pixels off (nan {int(bad_nan.sum())}, zero-mask {int(bad_zero.sum())}, "
+                             f"rel {int(bad_rel.sum())} max {rel[strict].max() if strict.any() else 0:.3e}, outside envelope "
+                             f"{int(bad_env.sum())}); first: {detail}")
+    return float(rel[strict].max()) if strict.any() else 0.0
 
 
 def assert_mrf_close(got, ref, what="MRF", rtol=1e-4):

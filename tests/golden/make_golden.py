@@ -57,7 +57,7 @@ def main():
     full["depth_crc32"] = crc(depth)
     full["smooth_crc32"] = crc(smooth)
     full["jbf"] = stats(filt)
-    full["jbf_ill"] = int((ill & 1).sum())
+    full["jbf_flagged"] = int(ill.flagged.sum())   # pixels compared with the envelope instead of the float32 value
     full["points"] = stats(pts.view(np.float32))
     full["sp_labels_crc32"] = crc(rg["sp_labels"])
     full["dasp_labels_crc32"] = crc(rg["dasp_labels"])
@@ -72,9 +72,13 @@ def main():
     Kc = synth.intrinsics(64, 48)
     g = {"bgr": cb, "depth": cd}
     g["k0_smooth"] = O.cv_bilateral(cb, 5, 30.0, 30.0)
-    g["k1_jbf_ref_params"], g["k1_jbf_ref_params_ill"] = O.jbf_kernel(cd, g["k0_smooth"], return_ill=True)
-    g["jbf_process"], _, g["jbf_process_ill"] = O.jbf_process(cd, cb, return_all=True)
-    g["k1_jbf_w11_s3_c7p65"], g["k1_jbf_w11_s3_c7p65_ill"] = O.jbf_kernel(cd, cb, 11, 3.0, 7.65, 20.0, return_ill=True)
+    # every float depth output comes with its parity envelope (oracle.Env: <name>_flags / _lo / _hi)
+    g["k1_jbf_ref_params"], env = O.jbf_kernel(cd, g["k0_smooth"], return_ill=True)
+    g.update(env.to_dict("k1_jbf_ref_params"))
+    g["jbf_process"], _, env = O.jbf_process(cd, cb, return_all=True)
+    g.update(env.to_dict("jbf_process"))
+    g["k1_jbf_w11_s3_c7p65"], env = O.jbf_kernel(cd, cb, 11, 3.0, 7.65, 20.0, return_ill=True)
+    g.update(env.to_dict("k1_jbf_w11_s3_c7p65"))
     g["mrf"] = O.mrf_kernel(cd, cb)
     cp = O.p2r_depth(cd, Kc)
     g["k2_points"] = cp.view(np.float32).reshape(48, 64, 3)
@@ -98,7 +102,7 @@ def main():
     with O.ers_flags((48, 64)) as rill:
         r = O.rgbf_process(cd, cp, cb, 3, 4, Kc)
     g["rgbf_refined_depth"], g["rgbf_refined_labels"] = r["refined_depth"], r["refined_labels"]
-    g["rgbf_refined_depth_ill"] = rill.copy()
+    g.update(rill.to_dict("rgbf_refined_depth"))
     np.savez_compressed(os.path.join(HERE, "golden_crops.npz"), **g)
     print("wrote golden_fullframe.json and golden_crops.npz:",
           {k: (v.shape, str(v.dtype)) for k, v in g.items()})

@@ -29,7 +29,7 @@ def test_oracle_full_frame_checksums(oracle, color_fixture, synth):
     filt, smooth, ill = oracle.jbf_process(depth, color_fixture, return_all=True)
     assert _crc(smooth) == full["smooth_crc32"]
     assert _crc(filt) == full["jbf"]["crc32"] and int((filt == 0).sum()) == full["jbf"]["zeros"]
-    assert int((ill & 1).sum()) == full["jbf_ill"]
+    assert int(ill.flagged.sum()) == full["jbf_flagged"]
     pts = oracle.p2r_depth(depth, K)
     assert _crc(pts.view(np.float32)) == full["points"]["crc32"]
     rg = oracle.rgbf_process(depth, pts, color_fixture, 15, 20, K)

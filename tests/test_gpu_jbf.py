@@ -1,8 +1,9 @@
 """K0 / K1 / Process parity: HIP (through the C ABI) vs the CPU oracle.
 
 Bar: exact equality for K0's u8 output; for float depth <= 1e-4 relative on
-non-zero outputs with an identical zero / non-zero mask.  Pixels the oracle flags as
-ill-conditioned (every surviving weight denormal-scale) are excluded and must be rare."""
+non-zero outputs with an identical zero / non-zero mask.  No pixel is excluded: pixels the oracle's envelope
+flags (a tap on a Q1 decision, or the rounding of the first-pass average amplified beyond 2e-5) must lie inside
+the envelope of binary64 evaluations instead (conftest.assert_depth_close, oracle/kde_oracle.h okde_env)."""
 import os
 
 import numpy as np
@@ -63,8 +64,7 @@ def test_filter_k1_matches_oracle(torch_cuda, F, oracle, frame, cfg):
     out = torch_cuda.empty((1, 240, 320), dtype=torch_cuda.float32, device="cuda")
     jbf.filter_batch(dev(torch_cuda, depth[None]), dev(torch_cuda, bgr[None]), out)
     ref, ill = oracle.jbf_kernel(depth, bgr, cfg["w"], cfg["ss"], cfg["cs"], cfg["ds"], return_ill=True)
-    assert ill.astype(bool).mean() < 2e-2
-    assert_depth_close(host(out)[0], ref, RTOL, ill=ill, what=f"K1 {cfg}")
+    assert_depth_close(host(out)[0], ref, RTOL, ill=ill, what=f"K1 {cfg}", max_flagged=0.08)
     assert np.array_equal(jbf.spatial_table(), oracle.spatial_table(cfg["w"], cfg["ss"]))
 
 
@@ -230,13 +230,10 @@ def test_every_tuned_variant_matches_oracle(torch_cuda, F, oracle, frame, regime
             jbf.set_variant(v)
             out = torch_cuda.empty((1, h, w), dtype=torch_cuda.float32, device="cuda")
             jbf.filter_batch(dev(torch_cuda, depth[None]), dev(torch_cuda, bgr[None]), out)
-            # (reference sigmas with window 19 carry weight on all 361 taps: the float32-average uncertainty of the
-            #  probe grows with sqrt(n_eff), and the 70x50 frame is mostly depth edges)
-            assert ill.astype(bool).mean() < (2e-2 if w > 100 else 5e-2)
             # sigma_d = 4 mm is a stress regime: d(ln weight)/d(avg) = delta/sigma_d^2, so the last ulp of the
-            # window average (2e-4 mm at 3 m) already moves single weights by 1e-3; the bar there is 1e-3
-            tol = 1e-3 if regime == "depth-outliers" else RTOL
-            assert_depth_close(host(out)[0], ref, tol, ill=ill, what=f"variant {nm} {regime} {w}x{h}")
+            # window average (2e-4 mm at 3 m) already moves single weights by 1e-3.  The bar stays 1e-4: such
+            # pixels are flagged by the envelope's width and held to the envelope
+            assert_depth_close(host(out)[0], ref, RTOL, ill=ill, what=f"variant {nm} {regime} {w}x{h}", max_flagged=0.25)
 
 
 def test_variant_selection_errors(torch_cuda, F):

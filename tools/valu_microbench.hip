@@ -1,0 +1,194 @@
+// tools/valu_microbench.hip — what does one wave64 VALU instruction cost a gfx950 SIMD?
+//
+// K1 / K10 / MRF are instruction-issue bound, so their roofline is "VALU issue slots per second".  This program
+// measures the slot cost of every instruction kind those kernels are made of, at 1, 2, 4 and 8 waves per SIMD:
+// each wave runs N independent instructions of one kind between two s_memtime stamps (shader-clock ticks), and
+// cycles per instruction per SIMD = ticks / (N * waves per SIMD).  Mixtures show whether costs add
+// (e.g. whether a v_exp_f32 overlaps with packed math of the same or of another wave).
+//
+// Build + run on the GPU box:   hipcc --offload-arch=gfx950 -O2 -o gpurun_out/valu_microbench tools/valu_microbench.hip
+//                               gpurun_out/valu_microbench > profiles/r02_valu_microbench.txt
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x)                                                                                   \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "%s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return 1;                                                                              \
+        }                                                                                          \
+    } while (0)
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int kReps = 64;      // loop trips
+constexpr int kUnroll = 32;    // instructions (or instruction groups) per trip
+
+enum Kind { FMA, PK_FMA, PK_MUL, PK_ADD, EXP, RCP, DOT4, LSHL_ADD, ADD_U32, CNDMASK, MAX_F32,
+            MIX_EXP_4PK, MIX_EXP_2PK, MIX_EXP_1PK, MIX_DOT_LSHL_PK, MIX_K1_PASS1, NKINDS };
+const char* kNames[NKINDS] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_exp_f32", "v_rcp_f32",
+                              "v_dot4_u32_u8", "v_lshl_add_u32", "v_add_u32", "v_cndmask_b32", "v_max_f32",
+                              "1 v_exp_f32 + 4 v_pk_fma_f32", "1 v_exp_f32 + 2 v_pk_fma_f32", "1 v_exp_f32 + 1 v_pk_fma_f32",
+                              "1 v_dot4 + 1 v_lshl_add + 1 v_pk_fma", "K1 pass-1 unit: 2 dot4 + 2 lshl_add + 2 exp + 6 pk"};
+const int kPerGroup[NKINDS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 5, 3, 2, 3, 12};
+
+template <int KIND>
+__global__ void bench(uint64_t* ticks, float* sink, float seed)
+{
+    // eight independent chains per kind so that no instruction waits for the previous one
+    float a[8];
+    f2 p[8];
+    uint32_t u[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        a[i] = seed + (float)i * 0.001f + (float)threadIdx.x * 1e-6f;
+        p[i] = f2{a[i], a[i] + 0.5f};
+        u[i] = (uint32_t)threadIdx.x * 2654435761u + i;
+    }
+    const float c0 = seed * 0.999f, c1 = seed * 1e-3f;
+    const f2 pc0 = f2{c0, c0}, pc1 = f2{c1, c1};
+    __syncthreads();
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+    for (int r = 0; r < kReps; r++) {
+#pragma unroll
+        for (int k = 0; k < kUnroll; k++) {
+            const int i = k & 7;
+            if (KIND == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));
+            if (KIND == PK_FMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));
+            if (KIND == PK_MUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pc0));
+            if (KIND == PK_ADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pc1));
+            if (KIND == EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+            if (KIND == RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+            if (KIND == DOT4) asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
+            if (KIND == LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            if (KIND == ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            if (KIND == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c0));
+            if (KIND == MAX_F32) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
+            if (KIND == MIX_EXP_4PK) {
+                asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 1) & 7]) : "v"(pc0), "v"(pc1));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 2) & 7]) : "v"(pc0), "v"(pc1));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 3) & 7]) : "v"(pc0), "v"(pc1));
+            }
+            if (KIND == MIX_EXP_2PK) {
+                asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 1) & 7]) : "v"(pc0), "v"(pc1));
+            }
+            if (KIND == MIX_EXP_1PK) {
+                asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));
+            }
+            if (KIND == MIX_DOT_LSHL_PK) {
+                asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
+                asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[(i + 3) & 7]) : "v"(u[(i + 4) & 7]));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));
+            }
+            if (KIND == MIX_K1_PASS1) {
+                asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
+                asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(u[(i + 3) & 7]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
+                asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[(i + 4) & 7]) : "v"(u[(i + 5) & 7]));
+                asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[(i + 6) & 7]) : "v"(u[(i + 5) & 7]));
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pc1));
+                asm volatile("v_pk_add_f32 %0, %0, %1 clamp" : "+v"(p[(i + 1) & 7]) : "v"(pc1));
+                asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[(i + 2) & 7]) : "v"(pc0));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 3) & 7]) : "v"(pc0), "v"(pc1));
+                asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+                asm volatile("v_exp_f32 %0, %0" : "+v"(a[(i + 1) & 7]));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 4) & 7]) : "v"(pc0), "v"(pc1));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 5) & 7]) : "v"(pc0), "v"(pc1));
+            }
+        }
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y + (float)u[i];
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
+    if ((threadIdx.x & 63) == 0) ticks[wave] = t1 - t0;
+    if (s == 12345.678f) sink[0] = s;      // keeps every chain live
+}
+
+template <int KIND>
+int run_kind(int cus, uint64_t* d_ticks, float* d_sink, std::vector<uint64_t>& h)
+{
+    printf("%-52s", kNames[KIND]);
+    for (int wps : {1, 2, 4, 8}) {
+        // waves per SIMD = (threads per block / 256) * blocks per CU; 1024-thread blocks, two per CU for 8
+        const int threads = wps >= 4 ? 1024 : 256 * wps;
+        const int blocks = cus * (wps == 8 ? 2 : 1);
+        const int waves = blocks * threads / 64;
+        double best = 1e30;
+        for (int rep = 0; rep < 3; rep++) {
+            hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(threads), 0, 0, d_ticks, d_sink, 1.0001f);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipMemcpy(h.data(), d_ticks, sizeof(uint64_t) * waves, hipMemcpyDeviceToHost));
+            std::vector<uint64_t> v(h.begin(), h.begin() + waves);
+            std::nth_element(v.begin(), v.begin() + waves / 2, v.end());
+            const double per = (double)v[waves / 2] / ((double)kReps * kUnroll * kPerGroup[KIND] * wps);
+            best = std::min(best, per);
+        }
+        printf("  %6.2f", best);
+    }
+    printf("\n");
+    return 0;
+}
+
+int main()
+{
+    int dev = 0, cus = 0, clk = 0;
+    CHECK(hipGetDevice(&dev));
+    CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    CHECK(hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, dev));
+    uint64_t* d_ticks;
+    float* d_sink;
+    const int max_waves = cus * 2 * 16;
+    CHECK(hipMalloc(&d_ticks, sizeof(uint64_t) * max_waves));
+    CHECK(hipMalloc(&d_sink, 4));
+    std::vector<uint64_t> h(max_waves);
+    printf("# gfx950 VALU issue cost: median over waves of s_memtime ticks / (instructions x waves per SIMD)\n");
+    printf("# device %d: %d CUs, max clock %d kHz; every CU runs the same stream; s_memtime ticks at 100 MHz would read 24x lower\n", dev, cus, clk);
+    printf("# columns: cycles per instruction per SIMD at 1, 2, 4, 8 waves per SIMD\n");
+    printf("%-52s  %6s  %6s  %6s  %6s\n", "instruction", "1w", "2w", "4w", "8w");
+    if (run_kind<FMA>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<PK_FMA>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<PK_MUL>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<PK_ADD>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<EXP>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<RCP>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<DOT4>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<LSHL_ADD>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<ADD_U32>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<CNDMASK>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<MAX_F32>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<MIX_EXP_4PK>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<MIX_EXP_2PK>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<MIX_EXP_1PK>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<MIX_DOT_LSHL_PK>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<MIX_K1_PASS1>(cus, d_ticks, d_sink, h)) return 1;
+    // wall-clock cross-check of the tick unit: one long v_fma_f32 launch timed with events
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 200; i++) hipLaunchKernelGGL(bench<FMA>, dim3(cus * 2), dim3(1024), 0, 0, d_ticks, d_sink, 1.0001f);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    CHECK(hipMemcpy(h.data(), d_ticks, sizeof(uint64_t) * 64, hipMemcpyDeviceToHost));
+    printf("# cross-check: 200 launches of the 8-wave v_fma_f32 stream took %.3f ms wall = %.1f us each; a wave's stamps span %llu ticks\n",
+           ms, ms * 1000.0 / 200, (unsigned long long)h[0]);
+    printf("#   -> ticks per microsecond of kernel time ~ %.0f (the launch also holds launch overhead, so this is a lower bound of the tick rate)\n",
+           (double)h[0] / (ms * 1000.0 / 200));
+    return 0;
+}
