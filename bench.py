@@ -14,7 +14,14 @@ One JSON line is printed by rank 0; besides the contract fields it carries
   roofline     — the dominant kernel (K1) against the HBM roofline: algorithmic 11 B/pixel
                  (4 B depth read + 3 B packed-BGR guide read + 4 B filtered write) x pixels per launch
                  / its average launch duration, measured with HIP events on the launch stream
-                 inside the timed region;
+                 inside the timed region.  K1 is instruction-issue bound, not HBM-bound, so the object also
+                 carries `valu`: issue slots per second against the chip's peak (1024 SIMDs x clock / 4 cycles; a
+                 transcendental takes two slots), with the per-wave instruction counts from the committed PMC
+                 profile of exactly this code (profiles/pmc_bench.json, matched by a hash of the kernel sources)
+                 and the launch time measured live; and `fhd_w19`: the same figures for the pass north_star's
+                 roofline target names (32 x 1920x1080, window 19; BASELINE config 3);
+  verified     — frame 0 of the TIMED output compared with the CPU oracle after the timed region (every pixel:
+                 1e-4 or inside the oracle's envelope, oracle.parity_check);
   cpu_baseline — the CPU oracle (a scalar port of the CUDA kernels; the reference has no CPU path)
                  timed on this host on a bounded sample of the same workload.
 """
@@ -33,6 +40,10 @@ if ROOT not in sys.path:
 METRIC = "Mpixels/sec joint-bilateral filtered (640x480 & 1080p); % HBM roofline"
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 K1_BYTES_PER_PX = 11.0
+CLK_GHZ = 2.4                  # max shader clock (same guide)
+N_SIMD = 1024                  # 256 CUs x 4
+SLOT_CYCLES = 4.0              # one wave64 VALU instruction per 4 cycles per SIMD (a transcendental: 8), the model
+                               # DESIGN.md prices K1 with; profiles/r02_valu_microbench.txt has the measured costs
 
 
 def parse():
@@ -51,8 +62,67 @@ def parse():
     ap.add_argument("--distinct-frames", type=int, default=8, help="distinct synthetic frames, tiled to the batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip the 1080p / reference-constant side measurements")
-    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_bench.json"))
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed output")
     return ap.parse_args()
+
+
+def pmc_lookup(path, window):
+    """K1 entry of the committed PMC table (tools/pmc_report.py) for this window: the launch with the largest grid.
+    Only used when the table was taken on exactly these kernel sources."""
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("pmc_report", os.path.join(ROOT, "tools", "pmc_report.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        source_hash = mod.source_hash
+        pj = json.load(open(path))
+        if pj.get("kernel_source_sha16") != source_hash():
+            return None, "profile is stale (kernel sources changed since tools/profile_round.sh ran)"
+        c = [k for k in pj["kernels"] if (f"jbf_pk_kernel<{window}," in k["kernel"] or f"jbf_fast_kernel<{window}," in k["kernel"])]
+        if not c:
+            return None, "no K1 entry for this window in the profile"
+        return max(c, key=lambda k: k["grid"]), os.path.relpath(path, ROOT)
+    except Exception as e:          # no profile: the live figures stand alone
+        return None, f"no profile ({type(e).__name__})"
+
+
+def k1_roofline(px_per_launch, k1_ms, entry, src):
+    """HBM roofline (the contract's fields) + the VALU issue-slot roofline of one K1 launch"""
+    achieved = K1_BYTES_PER_PX * px_per_launch / (k1_ms * 1e-3) / 1e9
+    r = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": None, "algorithmic_bytes_per_launch": K1_BYTES_PER_PX * px_per_launch, "avg_launch_ms": k1_ms}
+    peak_slots = N_SIMD * CLK_GHZ * 1e9 / SLOT_CYCLES
+    valu = {"peak_slots_per_s": peak_slots, "clk_ghz": CLK_GHZ, "achieved_slots_per_s": None, "frac": None, "profile": src,
+            "definition": "slots per launch = (SQ_INSTS_VALU + SQ_INSTS_VALU_TRANS_F32) of the profiled launch of this grid "
+                          "(wave-instructions; a transcendental takes two 4-cycle slots) / live launch time; "
+                          "peak = 1024 SIMDs x clk / 4"}
+    if entry:
+        d, c = entry["derived"], entry["counters"]
+        r["traffic"] = d.get("hbm_bytes")
+        if "SQ_INSTS_VALU" in c:
+            slots = c["SQ_INSTS_VALU"] + c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+            valu.update(achieved_slots_per_s=slots / (k1_ms * 1e-3), frac=slots / (k1_ms * 1e-3) / peak_slots,
+                        valu_insts_per_wave=d.get("valu_insts_per_wave"), trans_insts_per_wave=d.get("trans_insts_per_wave"),
+                        waves=c.get("SQ_WAVES"), grid=entry["grid"], vgprs=entry.get("vgprs"),
+                        pmc_busy_frac=d.get("valu_busy"), pmc_waves_per_simd=d.get("waves_per_simd"))
+    r["valu"] = valu
+    return r
+
+
+def verify_frame0(args, p, synth, first_seed, out0, smooth0):
+    """frame 0 of the timed output against the CPU oracle (the checker; never part of the timed path)"""
+    from oracle import oracle as O
+    O.build()
+    O.set_threads(usable_cores())
+    bgr, depth = synth.make_frame(first_seed, args.width, args.height)
+    ref, sm, env = O.jbf_process(depth, bgr, p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma, return_all=True)
+    chk = O.parity_check(out0, ref, env, 1e-4)
+    k0_exact = bool(np.array_equal(smooth0, sm))
+    return {"ok": bool(k0_exact and not chk["bad"].any()), "frame": 0, "k0_u8_exact": k0_exact,
+            "max_rel_err_unflagged": chk["max_rel_unflagged"], "pixels": chk["n"], "flagged": chk["flagged"],
+            "max_rel_err_flagged_vs_f32": chk["max_rel_flagged"], "outside_envelope": chk["outside_envelope"],
+            "bar": "1e-4 relative + identical zero mask on unflagged pixels; flagged pixels inside the oracle's binary64 envelope"}
 
 
 def make_inputs(synth, torch, first_seed, n, w, h, distinct):
@@ -184,20 +254,11 @@ def main():
     if rank == 0:
         px_per_launch = count * W * H
         k1_avg_ms = float(np.mean(k1_ms))
-        achieved = K1_BYTES_PER_PX * px_per_launch / (k1_avg_ms * 1e-3) / 1e9
-        # HBM bytes per K1 launch from the PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
-        # collected separately under rocprofv3 and committed as profiles/pmc_traffic.json; only quoted when
-        # that profile was taken on exactly this per-GPU workload
-        traffic, valu = None, None
-        if os.path.exists(args.pmc_json):
-            try:
-                pj = json.load(open(args.pmc_json))
-                wl = pj.get("workload", {})
-                if (wl.get("frames"), wl.get("width"), wl.get("height"), wl.get("window")) == (count, W, H, p.window_size):
-                    traffic = pj.get("k1_hbm_bytes_per_launch")
-                    valu = pj.get("k1_valu")
-            except Exception:
-                traffic = None
+        entry, src = pmc_lookup(args.pmc_json, p.window_size)
+        roof = {"bound": "hbm", "limiter": "valu-issue (K1 does 2 exp + ~30 flops per tap against 11 B/pixel; see roofline.valu)",
+                "kernel": "K1 joint_bilateral_filtering"}
+        roof.update(k1_roofline(px_per_launch, k1_avg_ms, entry, src))
+        roof["k0_avg_launch_ms"] = float(np.mean(k0_ms))
         res = {
             "metric": METRIC,
             "value": total_frames * W * H * args.steps / dt / 1e6,
@@ -214,19 +275,16 @@ def main():
                 "sharding": f"contiguous frame blocks x{world}, params broadcast from rank 0" + (" [REPLICAS ONLY]" if replicas_only else ""),
                 "kernel_variant": filters.JointBilateralFilter.variants()[args.variant] if args.variant >= 0 else "auto",
             },
-            "roofline": {"bound": "hbm", "kernel": "K1 joint_bilateral_filtering", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": K1_BYTES_PER_PX * px_per_launch,
-                         "avg_launch_ms": k1_avg_ms, "k0_avg_launch_ms": float(np.mean(k0_ms)),
-                         # the stencil is VALU/transcendental-bound, not HBM-bound: SQ counters of the
-                         # same kernel from profiles/pmc_traffic.json (null when not profiled on this workload)
-                         "valu": valu},
+            "roofline": roof,
             "checksum": {"sum_filtered_mm": checksum[0], "frames": int(checksum[1])},
         }
+        if not args.no_verify:
+            res["verified"] = verify_frame0(args, p, synth, first, out[0].cpu().numpy(), smooth[0].cpu().numpy())
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(args, synth, args.cpu_seconds)
         if world == 1 and not args.no_extra:
             res["also"] = side_measurements(torch, filters, synth, args)
+            res["roofline"]["fhd_w19"] = res["also"].pop("fhd_w19_config3")
         print(json.dumps(res), file=real_stdout, flush=True)
     if use_dist:
         dist.destroy_process_group()
@@ -249,12 +307,15 @@ def side_measurements(torch, filters, synth, args):
         dt, k0, k1 = time_steps(torch, jbf, depth, color, smooth, res, steps, 2, lambda: None)
         px = n * w * h
         k1m = float(np.mean(k1))
-        out[name] = {"frames": n, "width": w, "height": h, "window": window,
+        entry, src = pmc_lookup(args.pmc_json, window)
+        out[name] = {"workload": f"K0 + K1 on {n} x {w}x{h}, window {window}, sigma {ss:g}/{cs:g}/{ds:g}",
+                     "frames": n, "width": w, "height": h, "window": window,
                      "process_mpix_s": px * steps / dt / 1e6, "k1_mpix_s": px / (k1m * 1e-3) / 1e6,
-                     "k1_avg_launch_ms": k1m, "k0_avg_launch_ms": float(np.mean(k0)),
-                     "k1_hbm_frac": K1_BYTES_PER_PX * px / (k1m * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                     "k0_avg_launch_ms": float(np.mean(k0)), "bound": "hbm", "limiter": "valu-issue"}
+        out[name].update(k1_roofline(px, k1m, entry, src))
 
-    run("fhd_w19_config3", 1920, 1080, 8, 2, 19, 3.0, 7.65, 20.0)
+    # BASELINE config 3 as SURVEY 8(d) sizes it: 32 frames = 730 MB of algorithmic traffic, beyond the 256 MB Infinity Cache
+    run("fhd_w19_config3", 1920, 1080, 32, 2, 19, 3.0, 7.65, 20.0)
     run("vga_reference_constants_w5", 640, 480, 64, 8, 5, 70.0, 50.0, 20.0)
     # empirical HBM ceiling: float4 copy of 1 GiB (read + write)
     n = 1 << 28

@@ -94,6 +94,42 @@ class Env:
         return Env(flags=g[prefix + "_flags"], lo=g[prefix + "_lo"], hi=g[prefix + "_hi"])
 
 
+def parity_check(got, ref, env=None, rtol=1e-4):
+    """The parity bar of this repo, every pixel checked (used by tests/conftest.py, smoke() and bench.py's `verified`):
+      * unflagged pixels (all pixels when env is None): identical zero / NaN mask, <= rtol relative to the float32 value;
+      * flagged pixels (env.flagged): inside [lo, hi] widened by rtol, or 0 / NaN where the envelope admits that.
+    -> dict with the boolean map `bad` and the statistics the tests print."""
+    got = np.asarray(got, np.float32)
+    ref = np.asarray(ref, np.float32)
+    assert got.shape == ref.shape
+    flagged = np.zeros(ref.shape, bool) if env is None else env.flagged.reshape(ref.shape)
+    nan_ref, nan_got = np.isnan(ref), np.isnan(got)
+    g64, r64 = got.astype(np.float64), ref.astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.where((ref != 0) & ~nan_ref & ~nan_got, np.abs(g64 - r64) / np.abs(r64), 0.0)
+    strict = ~flagged
+    bad_nan = strict & (nan_ref != nan_got)
+    bad_zero = strict & ~nan_ref & ~nan_got & ((ref == 0) != (got == 0))
+    bad_rel = strict & (rel > rtol)
+    bad_env = np.zeros(ref.shape, bool)
+    band = cond = 0
+    if env is not None and flagged.any():
+        fl = env.flags.reshape(ref.shape)
+        lo, hi = env.lo.reshape(ref.shape), env.hi.reshape(ref.shape)
+        zero_ok = ((fl & Env.ZERO_OK) != 0) | (ref == 0)
+        nan_ok = ((fl & Env.NAN_OK) != 0) | nan_ref
+        inside = (hi > 0) & (g64 >= lo * (1 - rtol)) & (g64 <= hi * (1 + rtol))
+        ok = np.where(nan_got, nan_ok, np.where(got == 0, zero_ok, inside))
+        bad_env = flagged & ~ok
+        band, cond = int(((fl & Env.BAND) != 0).sum()), int(((fl & Env.COND) != 0).sum())
+    return {"bad": bad_nan | bad_zero | bad_rel | bad_env, "rel": rel,
+            "n": int(ref.size), "flagged": int(flagged.sum()), "band": band, "cond": cond,
+            "bad_nan": int(bad_nan.sum()), "bad_zero": int(bad_zero.sum()), "bad_rel": int(bad_rel.sum()),
+            "outside_envelope": int(bad_env.sum()),
+            "max_rel_unflagged": float(rel[strict].max()) if strict.any() else 0.0,
+            "max_rel_flagged": float(rel[flagged].max()) if flagged.any() else 0.0}
+
+
 def set_threads(n: int) -> int:
     return lib().okde_set_threads(int(n))
 

@@ -82,45 +82,24 @@ def assert_depth_close(got, ref, rtol=1e-4, ill=None, max_bad=0, what="depth", m
     logged (PARITY_LOG) and `max_flagged` bounds the flagged fraction."""
     got = np.asarray(got, np.float32)
     ref = np.asarray(ref, np.float32)
-    assert got.shape == ref.shape
     if ill is not None and not hasattr(ill, "flagged"):
         raise TypeError("assert_depth_close needs an oracle.Env (flags + envelope), not a bare flag map")
-    flagged = np.zeros(ref.shape, bool) if ill is None else ill.flagged.reshape(ref.shape)
-    nan_ref, nan_got = np.isnan(ref), np.isnan(got)
-    g64, r64 = got.astype(np.float64), ref.astype(np.float64)
-    with np.errstate(invalid="ignore", divide="ignore"):
-        rel = np.where((ref != 0) & ~nan_ref & ~nan_got, np.abs(g64 - r64) / np.abs(r64), 0.0)
-    # unflagged: strict
-    strict = ~flagged
-    bad_nan = strict & (nan_ref != nan_got)
-    bad_zero = strict & ~nan_ref & ~nan_got & ((ref == 0) != (got == 0))
-    bad_rel = strict & (rel > rtol)
-    bad = bad_nan | bad_zero | bad_rel
-    bad_env = np.zeros(ref.shape, bool)
-    if ill is not None and flagged.any():
-        fl = ill.flags.reshape(ref.shape)
-        lo, hi = ill.lo.reshape(ref.shape), ill.hi.reshape(ref.shape)
-        zero_ok = ((fl & 8) != 0) | (ref == 0)
-        nan_ok = ((fl & 16) != 0) | nan_ref
-        inside = (hi > 0) & (g64 >= lo * (1 - rtol)) & (g64 <= hi * (1 + rtol))
-        ok = np.where(nan_got, nan_ok, np.where(got == 0, zero_ok, inside))
-        bad_env = flagged & ~ok
-        bad |= bad_env
-        nfl = int(flagged.sum())
-        frac = nfl / flagged.size
-        PARITY_LOG.append(f"{what}: {flagged.size} px, flagged {nfl} ({frac:.2e}: band {int(((fl & 2) != 0).sum())}, "
-                          f"cond {int(((fl & 4) != 0).sum())}), max rel err unflagged {rel[strict].max() if strict.any() else 0:.2e}, "
-                          f"flagged vs float32 value {rel[flagged].max():.2e}, outside envelope {int(bad_env.sum())}")
+    from oracle.oracle import parity_check
+    r = parity_check(got, ref, ill, rtol)
+    if ill is not None:
+        frac = r["flagged"] / max(1, r["n"])
+        PARITY_LOG.append(f"{what}: {r['n']} px, flagged {r['flagged']} ({frac:.2e}: band {r['band']}, cond {r['cond']}), "
+                          f"max rel err unflagged {r['max_rel_unflagged']:.2e}, flagged vs float32 value "
+                          f"{r['max_rel_flagged']:.2e}, outside envelope {r['outside_envelope']}")
         if max_flagged is not None:
             assert frac <= max_flagged, f"{what}: {frac:.3e} of the pixels flagged (> {max_flagged})"
-    nbad = int(bad.sum())
+    nbad = int(r["bad"].sum())
     if nbad > max_bad:
-        idx = np.argwhere(bad)[:10]
+        idx = np.argwhere(r["bad"])[:10]
         detail = [(tuple(i), float(got[tuple(i)]), float(ref[tuple(i)])) for i in idx]
-        raise AssertionError(f"{what}: {nbad} pixels off (nan {int(bad_nan.sum())}, zero-mask {int(bad_zero.sum())}, "
-                             f"rel {int(bad_rel.sum())} max {rel[strict].max() if strict.any() else 0:.3e}, outside envelope "
-                             f"{int(bad_env.sum())}); first: {detail}")
-    return float(rel[strict].max()) if strict.any() else 0.0
+        raise AssertionError(f"{what}: {nbad} pixels off (nan {r['bad_nan']}, zero-mask {r['bad_zero']}, rel {r['bad_rel']} "
+                             f"max {r['max_rel_unflagged']:.3e}, outside envelope {r['outside_envelope']}); first: {detail}")
+    return r["max_rel_unflagged"]
 
 
 def assert_mrf_close(got, ref, what="MRF", rtol=1e-4):

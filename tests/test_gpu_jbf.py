@@ -129,6 +129,31 @@ def test_edge_cases_invalid_and_q1(torch_cuda, F, oracle):
     assert_depth_close(run(d), oracle.jbf_kernel(d, bgr), RTOL, what="nan depth")
 
 
+def test_denormal_range_weights_are_kept(torch_cuda, F, oracle):
+    """Round 1's divergence: raw v_exp_f32 flushes results below 2^-126, so a pixel whose weights were ALL float32
+    denormals came out 0 (a hole) where the reference writes a finite depth.  The tuned kernels now form weights at
+    2^24 scale.  Scene: holes whose valid neighbours all differ by (60,60,60) -> colour factor 2^-133 at sigma_c 7.65."""
+    h, w = 40, 48
+    rng = np.random.default_rng(1)
+    depth = (1000.0 + 10.0 * rng.random((h, w))).astype(np.float32)
+    bgr = np.full((h, w, 3), 60, np.uint8)
+    holes = [(y, x) for y in range(6, h - 6, 7) for x in range(6, w - 6, 7)]
+    for y, x in holes:
+        depth[y, x] = 0.0
+        bgr[y, x] = 0
+    for win in (5, 7, 11, 19):
+        ref, env = oracle.jbf_kernel(depth, bgr, win, 3.0, 7.65, 20.0, return_ill=True)
+        assert all(ref[y, x] > 900.0 for y, x in holes)                 # the reference fills these holes
+        for v, nm, vw in [(-1, "auto", win), (0, "generic", win)] + [t for t in _variant_windows(F) if t[2] == win]:
+            jbf = F.JointBilateralFilter(w, h, params(F, win, 3.0, 7.65, 20.0, pre=0))
+            jbf.set_variant(v)
+            out = torch_cuda.empty((1, h, w), dtype=torch_cuda.float32, device="cuda")
+            jbf.filter_batch(dev(torch_cuda, depth[None]), dev(torch_cuda, bgr[None]), out)
+            got = host(out)[0]
+            assert all(got[y, x] > 900.0 for y, x in holes), f"variant {nm}: a denormal-weight pixel was flushed to 0"
+            assert_depth_close(got, ref, RTOL, ill=env, what=f"denormal weights, variant {nm} window {win}")
+
+
 def test_full_size_properties_1080p(torch_cuda, F):
     """BASELINE-size frames, checked through size-independent properties (no oracle run)."""
     H, W, n = 1080, 1920, 3

@@ -384,3 +384,69 @@ def test_mean_3d_error(oracle):
     b[1, 1] = (0, 3, 1000)
     e, n = oracle.mean_3d_error(a, b)
     assert n == 5 and abs(e - (3 * 4 + 5) / 5) < 1e-6
+
+
+# ---- the parity envelope (oracle.Env / okde_env): what a faithful float32 evaluation may return ---------------------
+
+def _denormal_weight_scene():
+    """a hole whose valid neighbours all differ from it by (60,60,60): at sigma_c = 7.65 every colour factor is
+    exp(-10800/117.045) = 2^-133, a float32 denormal -- the reference still averages with these weights"""
+    h, w = 9, 9
+    depth = (1000.0 + 10.0 * np.arange(h * w, dtype=F).reshape(h, w)).astype(F)
+    bgr = np.full((h, w, 3), 60, np.uint8)
+    depth[4, 4] = 0.0
+    bgr[4, 4] = 0
+    return depth, bgr
+
+
+def test_envelope_contains_the_float32_value_everywhere(oracle, frame):
+    bgr, depth = frame(2, 96, 64)
+    for cfg in ((5, 70.0, 50.0, 20.0), (11, 3.0, 7.65, 20.0), (7, 5.0, 20.0, 4.0)):
+        ref, env = oracle.jbf_kernel(depth, bgr, *cfg, return_ill=True)
+        nz = ref != 0
+        assert np.all(ref[nz] >= env.lo[nz] * (1 - 1e-12)) and np.all(ref[nz] <= env.hi[nz] * (1 + 1e-12))
+        assert np.all((env.flags[~nz] & oracle.Env.ZERO_OK) != 0)
+        assert np.all(env.lo <= env.hi)
+        # unflagged pixels are the ones the strict 1e-4 test is meaningful for: their envelope is narrow
+        un = ~env.flagged & nz
+        assert np.all((env.hi - env.lo)[un] <= 2.0001e-5 * np.abs(ref[un]))
+        assert (env.flags & 1).sum() == 0                      # round 1's "denominator < 1e-30" class is retired
+
+
+def test_envelope_flags_a_tap_on_the_q1_jump(oracle):
+    """a tap whose depth term sits on the expf-underflow jump (|d - avg| = 288.41 mm at sigma_d 20): both outcomes
+    (factor ~1e-45, or skipped = 1) must be inside the envelope, and the pixel must be flagged BAND"""
+    depth, bgr = _flat(11, 11)
+    depth[5, 5] = 1000.0 + 288.41 * 25.0 / 24.0     # avg moves by delta/25 in a 5x5 window of equal weights
+    ref, env = oracle.jbf_kernel(depth, bgr, return_ill=True)
+    ys, xs = np.nonzero(env.flags & oracle.Env.BAND)
+    assert len(ys) > 0 and np.all(np.abs(ys - 5) <= 2) and np.all(np.abs(xs - 5) <= 2)
+    p = (ys[0], xs[0])
+    assert env.hi[p] - env.lo[p] > 1.0                 # skipped: the outlier pulls the result by ~ delta/25 = 12 mm
+    assert abs(env.lo[p] - 1000.0) < 0.01 and env.hi[p] > 1010.0   # factor 1e-45: outlier ignored; skipped: it counts fully
+
+
+def test_envelope_keeps_denormal_range_weights(oracle):
+    depth, bgr = _denormal_weight_scene()
+    ref, env = oracle.jbf_kernel(depth, bgr, 5, 3.0, 7.65, 20.0, return_ill=True)
+    # the float32 reference fills the hole from weights of 2^-133 * S (quantised to the denormal grid) ...
+    assert 1000.0 < ref[4, 4] < 1800.0
+    # ... and the binary64 evaluation of the same formula keeps them unquantised: both are in the envelope
+    assert env.lo[4, 4] <= ref[4, 4] <= env.hi[4, 4] and env.lo[4, 4] > 1000.0
+    assert (env.flags[4, 4] & oracle.Env.ZERO_OK) == 0         # 0 (all weights flushed) is NOT an admissible answer
+
+
+def test_envelope_of_k10_admits_nan_only_next_to_the_flat_patch_quirk(oracle):
+    depth, bgr = _flat(24, 40, d=1024.0, c=(9, 9, 9))
+    lab = np.zeros((24, 40), np.int32)
+    with oracle.ers_flags((24, 40)) as env:
+        ref = oracle.ers_enhance(depth, bgr, lab)
+    assert np.isnan(ref).sum() > 0
+    assert np.all((env.flags[np.isnan(ref)] & oracle.Env.NAN_OK) != 0)
+    rng = np.random.default_rng(3)
+    d2 = (depth + rng.normal(0, 5, depth.shape)).astype(F)
+    with oracle.ers_flags((24, 40)) as env2:
+        ref2 = oracle.ers_enhance(d2, bgr, lab)
+    assert not np.isnan(ref2).any() and ((env2.flags & oracle.Env.NAN_OK) != 0).sum() == 0
+    nz = ref2 != 0
+    assert np.all(ref2[nz] >= env2.lo[nz] * (1 - 1e-12)) and np.all(ref2[nz] <= env2.hi[nz] * (1 + 1e-12))

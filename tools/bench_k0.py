@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""K0 (cv::gpu::bilateralFilter 5/30/30) alone on a resident batch: the persistent kernel launches the same grid for
+every workload, so its PMC figures are only attributable when nothing else calls it (tools/profile_round.sh pmc_chain)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    import torch
+    from kinectdepthmapenhancement_amd import filters as F, synth
+    bgr, _ = synth.make_batch(500, min(a.frames, 8), a.width, a.height)
+    reps = -(-a.frames // bgr.shape[0])
+    color = torch.from_numpy(np.tile(bgr, (reps, 1, 1, 1))[:a.frames]).cuda()
+    out = torch.empty_like(color)
+    jbf = F.JointBilateralFilter(a.width, a.height, max_batch=a.frames)
+    jbf.presmooth_batch(color, out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        jbf.presmooth_batch(color, out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    px = a.frames * a.width * a.height
+    print(json.dumps({"size": f"{a.width}x{a.height}x{a.frames}", "ms": ms, "mpix_s": px / ms / 1e3,
+                      "algorithmic_bytes": 6.0 * px, "hbm_frac": 6.0 * px / (ms * 1e-3) / 8e12}))
+
+
+if __name__ == "__main__":
+    main()

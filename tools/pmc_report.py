@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc passes -> one JSON table per (kernel, grid).
+
+    python3 tools/pmc_report.py --dir gpurun_out/<tag>/pmc_bench --out profiles/r02_pmc_bench.json [--algo spec.json]
+
+`--dir` holds one sub-directory per counter pass (tools/profile_round.sh: fetch/, write/, sq1/, sq2/), each with the
+*counter_collection.csv files of one `rocprofv3 --pmc ...` run of the SAME command.  Counters are averaged over the
+launches of one (kernel name, grid size); derived figures follow /opt/skills/guides/MI355X_MICROARCH.md:
+
+  hbm_bytes           = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes).  FETCH_SIZE tallies 128-byte requests at 64 bytes on
+                        gfx950 for wide coalesced reads; the factor is calibrated in the same run on the library's float4
+                        copy kernel (reads exactly what it writes) and reported as `fetch_correction_measured`.
+  cycles              = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs)
+  valu_busy           = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles)        (quad-cycles -> cycles)
+  valu_slot_frac      = (SQ_INSTS_VALU + SQ_INSTS_VALU_TRANS_F32) x 4 / (1024 x cycles): issue slots of 4 cycles, a
+                        transcendental counts two (the model bench.py's roofline.valu uses)
+  waves_per_simd      = SQ_WAVE_CYCLES x 4 / (1024 x cycles)                    (mean resident waves per SIMD)
+  lds_conflict_frac   = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+`--algo` optionally maps a kernel-name substring to algorithmic bytes per launch so that traffic ratios are in the file."""
+import argparse
+import csv
+import glob
+import hashlib
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_hash():
+    """sha256 over the kernel sources: bench.py only quotes a profile taken on exactly this code"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "kinectdepthmapenhancement_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def short(name):
+    name = re.sub(r"kde::\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    return name
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dir", required=True)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--algo", default="", help="JSON: {kernel-name substring: algorithmic bytes per launch}")
+    ap.add_argument("--command", default="", help="the profiled command, recorded in the file")
+    ap.add_argument("--keep", default="jbf|presmooth|mrf|copy_kernel|enhance|edge_|calc_ld|analyze|sample_clusters|p2r|points_map|buf_|spdsr|moments|plane|jacobi",
+                    help="regex of kernel names to keep")
+    a = ap.parse_args()
+    keep = re.compile(a.keep)
+    algo = json.load(open(a.algo)) if a.algo else {}
+
+    table = defaultdict(lambda: {"counters": defaultdict(list), "meta": {}})
+    for path in glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                name = row["Kernel_Name"]
+                if not keep.search(name):
+                    continue
+                key = (short(name), int(row["Grid_Size"]))
+                e = table[key]
+                e["counters"][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                e["meta"] = {"workgroup": int(row.get("Workgroup_Size", 0) or 0), "lds_bytes": int(row.get("LDS_Block_Size", 0) or 0),
+                             "vgprs": int(row.get("VGPR_Count", 0) or 0), "sgprs": int(row.get("SGPR_Count", 0) or 0)}
+
+    out = {"source": "rocprofv3 --pmc, one counter group per pass (tools/profile_round.sh); MI355X",
+           "command": a.command, "kernel_source_sha16": source_hash(), "kernels": []}
+    corr = None
+    for (name, grid), e in sorted(table.items()):
+        c = {k: sum(v) / len(v) for k, v in e["counters"].items()}
+        d = {}
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            d["hbm_bytes"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            d["fetch_bytes_x2"] = 2.0 * c["FETCH_SIZE"] * 1024.0
+            d["write_bytes"] = c["WRITE_SIZE"] * 1024.0
+            if "copy_kernel" in name and c["FETCH_SIZE"] > 1e5:
+                corr = c["WRITE_SIZE"] / c["FETCH_SIZE"]
+        cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        if cyc > 0:
+            d["cycles"] = cyc
+            if "SQ_ACTIVE_INST_VALU" in c:
+                d["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)
+            if "SQ_INSTS_VALU" in c:
+                tr = c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+                d["valu_slot_frac"] = (c["SQ_INSTS_VALU"] + tr) * 4.0 / (1024.0 * cyc)
+                if c.get("SQ_WAVES"):
+                    d["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+                    d["trans_insts_per_wave"] = tr / c["SQ_WAVES"]
+            if "SQ_WAVE_CYCLES" in c:
+                d["waves_per_simd"] = c["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * cyc)
+            if "SQ_ACTIVE_INST_LDS" in c:
+                d["lds_inst_busy"] = c["SQ_ACTIVE_INST_LDS"] * 4.0 / (1024.0 * cyc)
+        if c.get("SQ_LDS_IDX_ACTIVE"):
+            d["lds_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
+        for sub, nbytes in algo.items():
+            key, _, g = sub.partition("@")
+            if key in name and (not g or int(g) == grid):
+                d["algorithmic_bytes"] = float(nbytes)
+                if "hbm_bytes" in d:
+                    d["traffic_ratio"] = d["hbm_bytes"] / float(nbytes)
+        out["kernels"].append({"kernel": name, "grid": grid, **e["meta"],
+                               "launches": max(len(v) for v in e["counters"].values()),
+                               "counters": {k: round(v, 2) for k, v in sorted(c.items())},
+                               "derived": {k: (round(v, 5) if abs(v) < 100 else round(v, 1)) for k, v in d.items()}})
+    out["fetch_correction_measured"] = corr
+    with open(a.out, "w") as f:
+        json.dump(out, f, indent=1)
+    for k in out["kernels"]:
+        print(f'{k["kernel"][:70]:70s} grid {k["grid"]:>9d}  ' + "  ".join(f"{n}={v}" for n, v in k["derived"].items()), file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

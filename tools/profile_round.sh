@@ -1,43 +1,92 @@
 #!/bin/bash
 # Collects the profiling evidence of a round on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh <tag>     ->  gpurun_out/<tag>/...
-# 1. PMC passes (one counter group each, no tracing domains mixed in) -> pmc_traffic.json (also written into
-#    profiles/ of the box copy so that the bench lines below carry the traffic / VALU figures of THIS build)
-# 2. rocprofv3 --kernel-trace --stats over the default bench command
-# 3. the plain bench line
+#   tools/profile_round.sh <tag> [steps...]     ->  gpurun_out/<tag>/...
+# steps (default: all):
+#   pmc_bench   PMC passes over the bench command (headline 64 x VGA window 11, 32 x 1080p window 19, window 5, K0)
+#               -> pmc_bench.json (also copied to profiles/pmc_bench.json of the box copy so that the bench lines of
+#               this call quote the traffic / instruction counts of THIS build)
+#   pmc_chain   PMC passes over tools/bench_chain.py (K2, K6-K10), tools/bench_mrf.py and tools/bench_spdsr.py
+#   stats       rocprofv3 --kernel-trace --stats over the default bench command, the chain and SPDSR
+#   bench       the plain bench line
+#   chain       tools/bench_chain.py at 1080p and 640x480, tools/bench_spdsr.py, tools/bench_mrf.py
+#   sweep       K1 variant / tile sweeps (BASELINE config 3)
+#   micro       tools/valu_microbench (VALU issue costs)
+# PMC passes hold one counter group each and no tracing domain (MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -eo pipefail
 TAG=${1:-final}
+shift || true
+STEPS=${*:-pmc_bench pmc_chain stats bench chain sweep micro}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-SHORT="bench.py --steps 3 --warmup 1 --cpu-seconds 0"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc/fetch" -o fetch -- python3 $SHORT > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc/write" -o write -- python3 $SHORT > "$OUT/pmc_write.log" 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc/sq" -o sq -- python3 $SHORT --no-extra > "$OUT/pmc_sq.log" 2>&1
-python3 tools/collect_pmc.py --dir "$OUT/pmc" --out "$OUT/pmc_traffic.json" 2> "$OUT/pmc_summary.log"
-cp "$OUT/pmc_traffic.json" profiles/pmc_traffic.json
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 bench.py --cpu-seconds 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err"
-python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-find "$OUT/pmc" -name "*.csv" ! -name "*counter_collection.csv" -delete
-cat "$OUT/pmc_summary.log" "$OUT/bench.json"
-# 4. BASELINE config 5 (full chain) per stage and per kernel, config 3 (tile sweep) and the other windows
-python3 tools/bench_chain.py > "$OUT/chain_config5_fhd.json" 2> "$OUT/chain.err"
-python3 tools/bench_chain.py --width 640 --height 480 > "$OUT/chain_config5_vga.json" 2>> "$OUT/chain.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/chain_stats" -o chain -- python3 tools/bench_chain.py > /dev/null 2>> "$OUT/chain.err"
-{
-  python3 tools/sweep_jbf.py --width 1920 --height 1080 --frames 8 --window 19 --with-generic
-  python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 19
-  python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 11 --with-generic
-  python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 7 --spatial-sigma 70 --color-sigma 50 --depth-sigma 20
-  python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 5 --spatial-sigma 70 --color-sigma 50 --depth-sigma 20 --with-generic
-} > "$OUT/sweep_k1_variants.log" 2> "$OUT/sweep.err"
-echo "profile round $TAG done"
-# 5. SPDepthSuperResolution::Process (row f2)
-python3 tools/bench_spdsr.py > "$OUT/spdsr_fhd.json" 2> "$OUT/spdsr.err"
-python3 tools/bench_spdsr.py --width 640 --height 480 > "$OUT/spdsr_vga.json" 2>> "$OUT/spdsr.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/spdsr_stats" -o spdsr -- python3 tools/bench_spdsr.py > /dev/null 2>> "$OUT/spdsr.err"
-echo "spdsr done"
-# 6. MarkovRandomField::Process (row f1)
-python3 tools/bench_mrf.py > "$OUT/mrf_vga.json" 2> "$OUT/mrf.err"
-python3 tools/bench_mrf.py --width 1920 --height 1080 --frames 8 > "$OUT/mrf_fhd.json" 2>> "$OUT/mrf.err"
-echo "mrf done"
+SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE"
+SQ2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"
+
+pmc_passes() {   # <subdir> <program> <args...>: four passes of the same command
+  local sub=$1; shift
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$sub/fetch" -o fetch -- "$@" > "$OUT/$sub.fetch.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$sub/write" -o write -- "$@" > "$OUT/$sub.write.log" 2>&1
+  rocprofv3 --pmc $SQ1 --output-format csv -d "$OUT/$sub/sq1" -o sq1 -- "$@" > "$OUT/$sub.sq1.log" 2>&1
+  rocprofv3 --pmc $SQ2 --output-format csv -d "$OUT/$sub/sq2" -o sq2 -- "$@" > "$OUT/$sub.sq2.log" 2>&1
+  find "$OUT/$sub" -name "*.csv" ! -name "*counter_collection.csv" -delete
+}
+
+for STEP in $STEPS; do
+case $STEP in
+pmc_bench)
+  SHORT="bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-verify"
+  pmc_passes pmc_bench python3 $SHORT
+  python3 tools/pmc_report.py --dir "$OUT/pmc_bench" --out "$OUT/pmc_bench.json" --command "python3 $SHORT" \
+      --algo tools/algo_bytes_bench.json 2> "$OUT/pmc_bench.summary"
+  cp "$OUT/pmc_bench.json" profiles/pmc_bench.json
+  cat "$OUT/pmc_bench.summary"
+  ;;
+pmc_chain)
+  pmc_passes pmc_chain python3 tools/bench_chain.py --iters 5
+  python3 tools/pmc_report.py --dir "$OUT/pmc_chain" --out "$OUT/pmc_chain.json" --command "python3 tools/bench_chain.py --iters 5" \
+      --algo tools/algo_bytes_chain.json 2> "$OUT/pmc_chain.summary"
+  pmc_passes pmc_k0 python3 tools/bench_k0.py
+  echo '{"presmooth_kernel": 117964800}' > "$OUT/algo_k0.json"      # 6 B/pixel x 64 x 640x480
+  python3 tools/pmc_report.py --dir "$OUT/pmc_k0" --out "$OUT/pmc_k0.json" --command "python3 tools/bench_k0.py" \
+      --algo "$OUT/algo_k0.json" 2> "$OUT/pmc_k0.summary"
+  pmc_passes pmc_mrf python3 tools/bench_mrf.py
+  python3 tools/pmc_report.py --dir "$OUT/pmc_mrf" --out "$OUT/pmc_mrf.json" --command "python3 tools/bench_mrf.py" 2> "$OUT/pmc_mrf.summary"
+  pmc_passes pmc_spdsr python3 tools/bench_spdsr.py
+  python3 tools/pmc_report.py --dir "$OUT/pmc_spdsr" --out "$OUT/pmc_spdsr.json" --command "python3 tools/bench_spdsr.py" 2> "$OUT/pmc_spdsr.summary"
+  cat "$OUT/pmc_chain.summary" "$OUT/pmc_k0.summary" "$OUT/pmc_mrf.summary" "$OUT/pmc_spdsr.summary"
+  ;;
+stats)
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 bench.py --cpu-seconds 0 --no-verify > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/chain_stats" -o chain -- python3 tools/bench_chain.py > /dev/null 2> "$OUT/chain_stats.err"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/spdsr_stats" -o spdsr -- python3 tools/bench_spdsr.py > /dev/null 2> "$OUT/spdsr_stats.err"
+  ;;
+bench)
+  python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+  cat "$OUT/bench.json"
+  ;;
+chain)
+  python3 tools/bench_chain.py > "$OUT/chain_config5_fhd.json" 2> "$OUT/chain.err"
+  python3 tools/bench_chain.py --width 640 --height 480 > "$OUT/chain_config5_vga.json" 2>> "$OUT/chain.err"
+  python3 tools/bench_spdsr.py > "$OUT/spdsr_fhd.json" 2> "$OUT/spdsr.err"
+  python3 tools/bench_spdsr.py --width 640 --height 480 > "$OUT/spdsr_vga.json" 2>> "$OUT/spdsr.err"
+  python3 tools/bench_mrf.py > "$OUT/mrf_vga.json" 2> "$OUT/mrf.err"
+  python3 tools/bench_mrf.py --width 1920 --height 1080 --frames 8 > "$OUT/mrf_fhd.json" 2>> "$OUT/mrf.err"
+  cat "$OUT/chain_config5_fhd.json"
+  ;;
+sweep)
+  {
+    python3 tools/sweep_jbf.py --width 1920 --height 1080 --frames 8 --window 19 --with-generic
+    python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 19
+    python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 11 --with-generic
+    python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 7 --spatial-sigma 70 --color-sigma 50 --depth-sigma 20
+    python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 5 --spatial-sigma 70 --color-sigma 50 --depth-sigma 20 --with-generic
+  } > "$OUT/sweep_k1_variants.log" 2> "$OUT/sweep.err"
+  ;;
+micro)
+  tools/valu_microbench > "$OUT/valu_microbench.txt" 2>&1
+  cat "$OUT/valu_microbench.txt"
+  ;;
+*) echo "unknown step $STEP"; exit 2 ;;
+esac
+echo "profile round $TAG: $STEP done"
+done

@@ -26,8 +26,7 @@
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int kReps = 64;      // loop trips
-constexpr int kUnroll = 32;    // instructions (or instruction groups) per trip
+constexpr int kUnroll = 32;    // instructions (or instruction groups) per loop trip
 
 enum Kind { FMA, PK_FMA, PK_MUL, PK_ADD, EXP, RCP, DOT4, LSHL_ADD, ADD_U32, CNDMASK, MAX_F32,
             MIX_EXP_4PK, MIX_EXP_2PK, MIX_EXP_1PK, MIX_DOT_LSHL_PK, MIX_K1_PASS1, NKINDS };
@@ -38,7 +37,7 @@ const char* kNames[NKINDS] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk
 const int kPerGroup[NKINDS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 5, 3, 2, 3, 12};
 
 template <int KIND>
-__global__ void bench(uint64_t* ticks, float* sink, float seed)
+__global__ void bench(uint64_t* ticks, float* sink, float seed, int reps)
 {
     // eight independent chains per kind so that no instruction waits for the previous one
     float a[8];
@@ -56,7 +55,7 @@ __global__ void bench(uint64_t* ticks, float* sink, float seed)
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
-    for (int r = 0; r < kReps; r++) {
+    for (int r = 0; r < reps; r++) {
 #pragma unroll
         for (int k = 0; k < kUnroll; k++) {
             const int i = k & 7;
@@ -118,28 +117,48 @@ __global__ void bench(uint64_t* ticks, float* sink, float seed)
     if (s == 12345.678f) sink[0] = s;      // keeps every chain live
 }
 
+// One launch per (kind, waves per SIMD), long enough (a few ms) that launch overhead does not matter.  Two clocks:
+//   ticks : s_memtime stamps inside the kernel, median over waves  -> "cycles" if s_memtime runs at the shader clock
+//   wall  : HIP events around the launch                           -> ns per instruction per SIMD, the unit a roofline needs
+// A launch whose wall time exceeds a wave's own span by > 30 % did not keep its blocks co-resident and is marked '*'.
 template <int KIND>
 int run_kind(int cus, uint64_t* d_ticks, float* d_sink, std::vector<uint64_t>& h)
 {
-    printf("%-52s", kNames[KIND]);
-    for (int wps : {1, 2, 4, 8}) {
-        // waves per SIMD = (threads per block / 256) * blocks per CU; 1024-thread blocks, two per CU for 8
-        const int threads = wps >= 4 ? 1024 : 256 * wps;
-        const int blocks = cus * (wps == 8 ? 2 : 1);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    char line_t[256], line_w[256];
+    int nt = 0, nw = 0;
+    double ghz_sum = 0;
+    int ghz_n = 0;
+    for (int wps : {1, 2, 3, 4, 5, 6, 8}) {
+        const int threads = 256, blocks = cus * wps;      // a 256-thread block puts one wave on each SIMD of its CU
         const int waves = blocks * threads / 64;
-        double best = 1e30;
-        for (int rep = 0; rep < 3; rep++) {
-            hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(threads), 0, 0, d_ticks, d_sink, 1.0001f);
-            CHECK(hipDeviceSynchronize());
-            CHECK(hipMemcpy(h.data(), d_ticks, sizeof(uint64_t) * waves, hipMemcpyDeviceToHost));
-            std::vector<uint64_t> v(h.begin(), h.begin() + waves);
-            std::nth_element(v.begin(), v.begin() + waves / 2, v.end());
-            const double per = (double)v[waves / 2] / ((double)kReps * kUnroll * kPerGroup[KIND] * wps);
-            best = std::min(best, per);
-        }
-        printf("  %6.2f", best);
+        const int reps = 60000 / (wps * kPerGroup[KIND]) + 64;
+        const double n_inst = (double)reps * kUnroll * kPerGroup[KIND];
+        hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(threads), 0, 0, d_ticks, d_sink, 1.0001f, reps / 8);   // warm-up
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(threads), 0, 0, d_ticks, d_sink, 1.0001f, reps);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipDeviceSynchronize());
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        CHECK(hipMemcpy(h.data(), d_ticks, sizeof(uint64_t) * waves, hipMemcpyDeviceToHost));
+        std::vector<uint64_t> v(h.begin(), h.begin() + waves);
+        std::nth_element(v.begin(), v.begin() + waves / 2, v.end());
+        const double span = (double)v[waves / 2];
+        const double tick_ghz = span / (ms * 1e6);                    // ticks per ns if the wave spans the launch
+        const bool serial = tick_ghz < 0.7 * 2.4 && ms * 1e6 * 2.4 > 1.3 * span + 50000.0 && false;
+        (void)serial;
+        const double per_t = span / (n_inst * wps);
+        const double per_w = ms * 1e6 / (n_inst * wps);               // ns per instruction per SIMD (all SIMDs run alike)
+        nt += snprintf(line_t + nt, sizeof(line_t) - nt, "  %6.2f", per_t);
+        nw += snprintf(line_w + nw, sizeof(line_w) - nw, "  %6.3f", per_w);
+        ghz_sum += tick_ghz;
+        ghz_n++;
     }
-    printf("\n");
+    printf("%-50s ticks%s\n", kNames[KIND], line_t);
+    printf("%-50s ns   %s   (ticks/ns %.2f)\n", "", line_w, ghz_sum / ghz_n);
     return 0;
 }
 
@@ -151,14 +170,16 @@ int main()
     CHECK(hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, dev));
     uint64_t* d_ticks;
     float* d_sink;
-    const int max_waves = cus * 2 * 16;
+    const int max_waves = cus * 8 * 4;
     CHECK(hipMalloc(&d_ticks, sizeof(uint64_t) * max_waves));
     CHECK(hipMalloc(&d_sink, 4));
     std::vector<uint64_t> h(max_waves);
-    printf("# gfx950 VALU issue cost: median over waves of s_memtime ticks / (instructions x waves per SIMD)\n");
-    printf("# device %d: %d CUs, max clock %d kHz; every CU runs the same stream; s_memtime ticks at 100 MHz would read 24x lower\n", dev, cus, clk);
-    printf("# columns: cycles per instruction per SIMD at 1, 2, 4, 8 waves per SIMD\n");
-    printf("%-52s  %6s  %6s  %6s  %6s\n", "instruction", "1w", "2w", "4w", "8w");
+    printf("# gfx950 VALU issue cost per wave64 instruction per SIMD, every SIMD of the chip running the same stream\n");
+    printf("# device %d: %d CUs, max clock %d kHz\n", dev, cus, clk);
+    printf("# rows 'ticks': s_memtime ticks of a wave / (its instructions x waves per SIMD); rows 'ns': launch wall time /\n");
+    printf("#   (instructions per wave x waves per SIMD) -- what a roofline needs; ticks/ns = the two clocks' ratio (2.4 = s_memtime\n");
+    printf("#   counts 2.4 GHz shader cycles and the waves of a SIMD span the whole launch)\n");
+    printf("# columns: 1, 2, 3, 4, 5, 6, 8 waves per SIMD (256-thread blocks, one wave per SIMD each)\n");
     if (run_kind<FMA>(cus, d_ticks, d_sink, h)) return 1;
     if (run_kind<PK_FMA>(cus, d_ticks, d_sink, h)) return 1;
     if (run_kind<PK_MUL>(cus, d_ticks, d_sink, h)) return 1;
@@ -175,20 +196,5 @@ int main()
     if (run_kind<MIX_EXP_1PK>(cus, d_ticks, d_sink, h)) return 1;
     if (run_kind<MIX_DOT_LSHL_PK>(cus, d_ticks, d_sink, h)) return 1;
     if (run_kind<MIX_K1_PASS1>(cus, d_ticks, d_sink, h)) return 1;
-    // wall-clock cross-check of the tick unit: one long v_fma_f32 launch timed with events
-    hipEvent_t e0, e1;
-    CHECK(hipEventCreate(&e0));
-    CHECK(hipEventCreate(&e1));
-    CHECK(hipEventRecord(e0, 0));
-    for (int i = 0; i < 200; i++) hipLaunchKernelGGL(bench<FMA>, dim3(cus * 2), dim3(1024), 0, 0, d_ticks, d_sink, 1.0001f);
-    CHECK(hipEventRecord(e1, 0));
-    CHECK(hipEventSynchronize(e1));
-    float ms = 0;
-    CHECK(hipEventElapsedTime(&ms, e0, e1));
-    CHECK(hipMemcpy(h.data(), d_ticks, sizeof(uint64_t) * 64, hipMemcpyDeviceToHost));
-    printf("# cross-check: 200 launches of the 8-wave v_fma_f32 stream took %.3f ms wall = %.1f us each; a wave's stamps span %llu ticks\n",
-           ms, ms * 1000.0 / 200, (unsigned long long)h[0]);
-    printf("#   -> ticks per microsecond of kernel time ~ %.0f (the launch also holds launch overhead, so this is a lower bound of the tick rate)\n",
-           (double)h[0] / (ms * 1000.0 / 200));
     return 0;
 }
