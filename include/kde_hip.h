@@ -98,7 +98,9 @@ int kde_jbf_filter_batch(kde_jbf* h, int n, const float* depth_dev, const uint8_
  * next Process or destroy */
 int kde_jbf_filtered_device(kde_jbf* h, float** out);
 /* float* getFiltered_Host() const (:44-46).  Unlike the reference (stale unless visualize() ran) the
- * pinned host copy is refreshed here: synchronises `stream` and copies frame 0..n_last-1. */
+ * pinned host copy is refreshed here: synchronises `stream` and copies the frames the last call wrote into the
+ * object's own Filtered_Device (at most max_batch).  Results a caller directed into its own buffer
+ * (filtered_dev != NULL) are not mirrored -- the object keeps no pointer to caller-owned memory. */
 int kde_jbf_filtered_host(kde_jbf* h, void* stream, const float** out);
 /* cv::gpu::GpuMat getSmoothImage_Device() (:47-49): object-owned packed BGR, step = 3*width */
 int kde_jbf_smooth_device(kde_jbf* h, uint8_t** out);
@@ -250,14 +252,6 @@ int kde_spdsr_optimized_points_device(kde_spdsr* h, kde_float3** out);          
 int kde_spdsr_optimized_points_host(kde_spdsr* h, void* stream, const kde_float3** out); /* getOptimizedPoints_Host (:59-61) */
 int kde_spdsr_plane_fitted_points_device(kde_spdsr* h, kde_float3** out);         /* Projection_GPU::GetPlaneFitted3D_Device (:56-58) */
 int kde_spdsr_cluster_nd_device(kde_spdsr* h, float** out);                       /* ClusterND_Device: float4 {normal, distance} per cluster */
-
-/* ============================================================================================
- * Measurement helpers (bench.py): a float4 streaming copy for the empirical HBM ceiling
- * ========================================================================================== */
-int kde_bench_copy(const void* src_dev, void* dst_dev, size_t bytes, void* stream);
-/* test hook: out_dev[i] = the kernels' square root of the integer first + i (i < n; first + n <= 2^24), so that the
- * tests can prove it equal to sqrtf() on every argument calculateLD can form (DepthAdaptiveSuperpixel.cu:213) */
-int kde_test_sqrt_int24(uint32_t first, uint32_t n, float* out_dev, void* stream);
 
 #ifdef __cplusplus
 }

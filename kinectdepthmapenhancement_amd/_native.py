@@ -122,8 +122,6 @@ SIGNATURES = {
     "kde_spdsr_optimized_points_host": (_i, [_vp, _vp, _pp]),
     "kde_spdsr_plane_fitted_points_device": (_i, [_vp, _pp]),
     "kde_spdsr_cluster_nd_device": (_i, [_vp, _pp]),
-    "kde_bench_copy": (_i, [_vp, _vp, _sz, _vp]),
-    "kde_test_sqrt_int24": (_i, [C.c_uint32, C.c_uint32, _vp, _vp]),
 }
 
 

@@ -11,6 +11,7 @@
 //      run as wavefront shuffles.
 //   All grids are ceil-div and bounds-guarded (D4); out-of-buffer taps of K6 read colour 0 (D1).
 #include "kde_internal.h"
+#include "kde_device_math.h"
 
 namespace kde {
 namespace {
@@ -89,19 +90,6 @@ __global__ __launch_bounds__(64) void sample_clusters_kernel(DaspGeom g, const u
         mean[id] = m;
         centers[id] = pts[(size_t)ay * g.width + ax];
     }
-}
-
-// sqrtf() of an integer-valued float in [0, 2^24): v_rsq_f32 estimate, one Heron step on the exact fma residual.
-// The library sqrtf() spends 14 instructions (denormal scaling, two +-1 ulp probes, class test) to be correctly
-// rounded for every float; on this domain 6 are enough -- tests/test_gpu_dasp_ers.py checks ALL 2^24 arguments
-// against sqrtf bit for bit (px*px + py*py of pixel offsets, the only argument K7 has, is such an integer).
-__device__ __forceinline__ float sqrt_int24(float x)
-{
-    const float y = __builtin_amdgcn_rsqf(x);          // 1/sqrt(x), 1 ulp; +inf for x == 0
-    const float r = x * y;
-    const float e = __builtin_fmaf(-r, r, x);          // exact residual x - r^2
-    const float r1 = __builtin_fmaf(e, 0.5f * y, r);
-    return x == 0.0f ? 0.0f : r1;
 }
 
 // ---- K7 calculateLD<16> (.cu:167-313) -------------------------------------------------------------
@@ -461,21 +449,7 @@ __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const
     }
 }
 
-// test hook: out[i] = sqrt_int24(first + i)
-__global__ __launch_bounds__(256) void sqrt_int24_probe_kernel(uint32_t first, uint32_t n, float* __restrict__ out)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) out[i] = sqrt_int24((float)(first + i));
-}
-
 }  // namespace
-
-int launch_sqrt_int24_probe(uint32_t first, uint32_t n, float* out, hipStream_t s)
-{
-    hipLaunchKernelGGL(sqrt_int24_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, first, n, out);
-    KDE_HIP_TRY(hipGetLastError());
-    return KDE_OK;
-}
 
 int launch_dasp_sample(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
                        kde_float3* centers, hipStream_t s)

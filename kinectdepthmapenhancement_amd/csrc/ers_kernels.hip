@@ -5,8 +5,9 @@
 // race-free GATHER with the snapshot semantics D2: in each phase (horizontal, then
 // vertical on the horizontal result) every source pixel evaluates its rule on the phase-start
 // labels/depth, its depth-zeroing cascade sees only its own writes, and write-sets are applied in
-// raster order of the source (later source wins).  A source at s writes at most [s-2, s+2] along the
-// scan, so output p inspects sources p+2 ... p-2 (descending = last writer first).
+// raster order of the source (later source wins).  A source at s finds its colour edge at distance d <= window/2
+// and writes at most [s-(d-1), s+(d-1)] along the scan, so output p inspects sources p+reach ... p-reach with
+// reach = window/2 - 1 (descending = last writer first); reach = 2 for the reference's window of 7.
 // K10 reads the K9 result and writes a separate buffer (D3).
 #include "kde_internal.h"
 
@@ -16,7 +17,7 @@ namespace {
 // -------------------------------------------------------------------------------------------------
 // K9 rule for ONE output position `pos` of a scan line of length `len` (.cu:4-102 in gather form):
 // L(k) / C(k) / D(k) read the phase-start depth label, colour label and depth at scan position k.
-// Reads stay inside [pos - 2 - half, pos + 2 + half] and [0, len).
+// Reads stay inside [pos - reach - half, pos + reach + half] and [0, len), reach = half - 1.
 // -------------------------------------------------------------------------------------------------
 template <typename FL, typename FC, typename FD>
 __device__ __forceinline__ void edge_rule(int pos, int len, int half, FL L, FC C, FD D, int32_t& out_label,
@@ -25,7 +26,8 @@ __device__ __forceinline__ void edge_rule(int pos, int len, int half, FL L, FC C
     out_label = L(pos);
     bool have_label = false;
     bool zero = false;
-    for (int s = pos + 2; s >= pos - 2; s--) {
+    const int reach = half > 1 ? half - 1 : 0;
+    for (int s = pos + reach; s >= pos - reach; s--) {
         if (s < 0 || s + 1 >= len) continue;
         if (L(s) == L(s + 1)) continue;
         const int cur = C(s);
@@ -870,15 +872,14 @@ int launch_ers_edge_refining(int width, int height, int window, const int32_t* c
                              const float* d0, int32_t* scratch_l, float* scratch_d, int32_t* l2, float* d2, bool two_launches,
                              hipStream_t s)
 {
-    const int H = window / 2 + 3;
-    const size_t ew = kEdgeTX + 2 * H, eh = kEdgeTY + 2 * H;
-    const size_t lds = ew * eh * 12 + (size_t)kEdgeTX * eh * 8;
-    if (!two_launches && window >= 0 && lds <= 64 * 1024) {
+    // The fused kernel's halo (window/2 + 3) and register window are laid out for the reference's window of 7
+    // (EdgeRefinedSuperpixel.cpp:4); any other window runs the two-launch form, whose rule takes any reach.
+    if (!two_launches && window / 2 == 3) {
+        const int H = window / 2 + 3;
+        const size_t ew = kEdgeTX + 2 * H, eh = kEdgeTY + 2 * H;
+        const size_t lds = ew * eh * 12 + (size_t)kEdgeTX * eh * 8;
         const dim3 grid(ceil_div(width, kEdgeTX), ceil_div(height, kEdgeTY));
-        if (window / 2 == 3)      // the reference's window (7): register-window form of the rule
-            hipLaunchKernelGGL(edge_fused_kernel<3>, grid, dim3(256), lds, s, width, height, window, color_labels, l0, d0, l2, d2);
-        else
-            hipLaunchKernelGGL(edge_fused_kernel<0>, grid, dim3(256), lds, s, width, height, window, color_labels, l0, d0, l2, d2);
+        hipLaunchKernelGGL(edge_fused_kernel<3>, grid, dim3(256), lds, s, width, height, window, color_labels, l0, d0, l2, d2);
         KDE_HIP_TRY(hipGetLastError());
         return KDE_OK;
     }

@@ -330,6 +330,41 @@ __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
     }
 }
 
+// K0 for any radius (OpenCV accepts any kernel size; the reference's call site uses 5): one thread per pixel, taps
+// read through the caches with reflect-101 addressing, weights from the same host-computed table (in global memory:
+// (radius^2 + 1) x 766 floats do not fit LDS beyond radius 4), same tap order / fma / IEEE division as the oracle.
+__global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_generic_kernel(PreDev a, int R)
+{
+    const int x = blockIdx.x * kPreBX + threadIdx.x % kPreBX, y = blockIdx.y * kPreBY + threadIdx.x / kPreBX;
+    if (x >= a.width || y >= a.height) return;
+    const size_t frame = (size_t)blockIdx.z * a.width * a.height;
+    const uint32_t cc = load_bgrx(a.src, frame + (size_t)y * a.width + x);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, sum2 = 0.0f;
+    for (int dy = -R; dy <= R; dy++) {
+        const int gy = reflect101(y + dy, a.height);
+        for (int dx = -R; dx <= R; dx++) {
+            const int space2 = dx * dx + dy * dy;
+            if (space2 > R * R) continue;
+            const uint32_t v = load_bgrx(a.src, frame + (size_t)gy * a.width + reflect101(x + dx, a.width));
+            const uint32_t n1 = __builtin_amdgcn_sad_u8(v, cc, 0u);
+            const float w = a.lut[(size_t)space2 * 766 + n1];
+            s0 = __builtin_fmaf(w, (float)(v & 0xffu), s0);
+            s1 = __builtin_fmaf(w, (float)((v >> 8) & 0xffu), s1);
+            s2 = __builtin_fmaf(w, (float)((v >> 16) & 0xffu), s2);
+            sum2 += w;
+        }
+    }
+    auto sat = [](float q) -> uint8_t {      // saturate_cast<uchar>: round half to even, clamp
+        if (!(q > 0.0f)) return 0;
+        if (q >= 255.0f) return 255;
+        return (uint8_t)rintf(q);
+    };
+    uint8_t* o = a.dst + (frame + (size_t)y * a.width + x) * 3;
+    o[0] = sat(s0 / sum2);
+    o[1] = sat(s1 / sum2);
+    o[2] = sat(s2 / sum2);
+}
+
 // --------------------------------------------------------------------------------------------
 // markov_random_field — MarkovRandomField/MarkovRandomField.cu:4-40
 // --------------------------------------------------------------------------------------------
@@ -432,21 +467,13 @@ int launch_jbf(const JbfLaunch& a, hipStream_t s)
     return KDE_OK;
 }
 
-int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
+// persistent-grid size of the tuned K0 kernels on the CURRENT device: every CU filled to the occupancy the variant
+// reaches (LDS table + VGPRs), no second wave.  Asked once per handle (kde_jbf_create) and kept there -- a handle
+// belongs to the device it was created on -- so nothing is cached across devices or threads here.
+constexpr int kPrePxPerThread = 2;                          // pixels per thread (A/B: 4)
+
+long long presmooth_resident_blocks(int radius)
 {
-    PreDev d;
-    d.src = a.src;
-    d.dst = a.dst;
-    d.lut = a.lut;
-    d.width = a.width;
-    d.height = a.height;
-    d.n = a.n;
-    constexpr int kPX = 2;                                  // pixels per thread (A/B: 4)
-    d.tiles_x = ceil_div(a.width, kPreBX * kPX);
-    d.tiles_y = ceil_div(a.height, kPreTH);
-    const long long total = (long long)d.tiles_x * d.tiles_y * a.n;
-    if (total > 0x7fffffffLL) return fail(KDE_ERR_INVALID, "presmooth: batch too large for one launch");
-    // persistent grid: every CU filled to the occupancy the variant reaches (LDS table + VGPRs), no second wave
     auto resident = [](auto kernel) -> long long {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -458,23 +485,44 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
         }
         return (long long)cus * per_cu;
     };
-    static long long slots[5] = {0, 0, 0, 0, 0};
-    if (a.radius >= 1 && a.radius <= 4 && slots[a.radius] == 0) {
-        switch (a.radius) {
-            case 1: slots[1] = resident(presmooth_kernel<1, kPX>); break;
-            case 2: slots[2] = resident(presmooth_kernel<2, kPX>); break;
-            case 3: slots[3] = resident(presmooth_kernel<3, kPX>); break;
-            default: slots[4] = resident(presmooth_kernel<4, kPX>); break;
-        }
+    switch (radius) {
+        case 1: return resident(presmooth_kernel<1, kPrePxPerThread>);
+        case 2: return resident(presmooth_kernel<2, kPrePxPerThread>);
+        case 3: return resident(presmooth_kernel<3, kPrePxPerThread>);
+        case 4: return resident(presmooth_kernel<4, kPrePxPerThread>);
+        default: return 0;                                  // generic kernel: a plain grid
     }
-    const long long cap = (a.radius >= 1 && a.radius <= 4) ? slots[a.radius] : 256;
+}
+
+int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
+{
+    PreDev d;
+    d.src = a.src;
+    d.dst = a.dst;
+    d.lut = a.lut;
+    d.width = a.width;
+    d.height = a.height;
+    d.n = a.n;
+    constexpr int kPX = kPrePxPerThread;
+    d.tiles_x = ceil_div(a.width, kPreBX * kPX);
+    d.tiles_y = ceil_div(a.height, kPreTH);
+    if (a.radius < 1) return fail(KDE_ERR_INVALID, "presmooth: radius %d", a.radius);
+    if (a.radius > 4) {
+        if (a.n > 65535) return fail(KDE_ERR_INVALID, "presmooth: batch too large for one launch");
+        hipLaunchKernelGGL(presmooth_generic_kernel, dim3(ceil_div(a.width, kPreBX), ceil_div(a.height, kPreBY), a.n),
+                           dim3(kPreBX * kPreBY), 0, s, d, a.radius);
+        KDE_HIP_TRY(hipGetLastError());
+        return KDE_OK;
+    }
+    const long long total = (long long)d.tiles_x * d.tiles_y * a.n;
+    if (total > 0x7fffffffLL) return fail(KDE_ERR_INVALID, "presmooth: batch too large for one launch");
+    const long long cap = a.grid_cap > 0 ? a.grid_cap : 256;
     const unsigned grid = (unsigned)(total < cap ? total : cap);
     switch (a.radius) {
         case 1: hipLaunchKernelGGL((presmooth_kernel<1, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
         case 2: hipLaunchKernelGGL((presmooth_kernel<2, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
         case 3: hipLaunchKernelGGL((presmooth_kernel<3, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
-        case 4: hipLaunchKernelGGL((presmooth_kernel<4, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
-        default: return fail(KDE_ERR_UNSUPPORTED, "presmooth: radius %d not built", a.radius);
+        default: hipLaunchKernelGGL((presmooth_kernel<4, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
     }
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;

@@ -41,8 +41,6 @@ void spatial_table(int window, float sigma, float* table)
         }
 }
 
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
 // smallest non-negative float q with q / den >= thr (float division); +inf if none
 static float smallest_q_reaching(float den, float thr)
 {
@@ -105,12 +103,12 @@ struct kde_jbf {
     DevBuf<float> pre_lut;          // K0 weight table
     PinnedBuf<float> filtered_host; // Filtered_Host
     int pre_radius = 0;
+    long long pre_grid_cap = 0;     // persistent-grid size of K0 on the device this handle was created on
     float color_den = 0, depth_den = 0;
     int cd_skip = INT_MAX;
     float d2_skip = INFINITY;
     int variant = -1;
-    int n_last = 0;
-    float* last_out = nullptr;
+    int n_last = 0;                 // frames of the last call that wrote Filtered_Device (0: none yet)
 };
 
 extern "C" int kde_jbf_default_params(kde_jbf_params* p)
@@ -127,7 +125,23 @@ extern "C" int kde_jbf_default_params(kde_jbf_params* p)
     return KDE_OK;
 }
 
+static int jbf_create_impl(kde_jbf** out, int width, int height, int max_batch, const kde_jbf_params* params);
+
 extern "C" int kde_jbf_create(kde_jbf** out, int width, int height, int max_batch, const kde_jbf_params* params)
+{
+    // the only entry point that builds std::vectors: nothing may cross the C boundary (kde_hip.h: "never aborts")
+    try {
+        return jbf_create_impl(out, width, height, max_batch, params);
+    } catch (const std::bad_alloc&) {
+        if (out) *out = nullptr;
+        return fail(KDE_ERR_NOMEM, "kde_jbf_create: out of host memory");
+    } catch (...) {
+        if (out) *out = nullptr;
+        return fail(KDE_ERR_INVALID, "kde_jbf_create: unexpected exception");
+    }
+}
+
+static int jbf_create_impl(kde_jbf** out, int width, int height, int max_batch, const kde_jbf_params* params)
 {
     KDE_REQUIRE(out, "kde_jbf_create: null out");
     *out = nullptr;
@@ -139,7 +153,11 @@ extern "C" int kde_jbf_create(kde_jbf** out, int width, int height, int max_batc
     KDE_REQUIRE(p.window_size >= 1 && p.window_size <= 31 && (p.window_size & 1), "kde_jbf_create: window_size must be odd in 1..31");
     KDE_REQUIRE(p.spatial_sigma == p.spatial_sigma && p.color_sigma >= 0.0f && p.depth_sigma >= 0.0f && p.spatial_sigma != 0.0f,
                 "kde_jbf_create: sigmas must be >= 0 (spatial != 0)");
-    kde_jbf* h = new (std::nothrow) kde_jbf;
+    struct Guard {                      // frees the half-built handle on every early return and on an exception
+        kde_jbf* h;
+        ~Guard() { delete h; }
+    } guard{new (std::nothrow) kde_jbf};
+    kde_jbf* h = guard.h;
     if (!h) return fail(KDE_ERR_NOMEM, "kde_jbf_create: out of host memory");
     h->width = width;
     h->height = height;
@@ -179,11 +197,11 @@ extern "C" int kde_jbf_create(kde_jbf** out, int width, int height, int max_batc
         ss_ = (ss_ <= 0) ? 1 : ss_;
         int radius = (p.presmooth_kernel_size <= 0) ? (int)rint((double)ss_ * 1.5) : p.presmooth_kernel_size / 2;
         radius = radius > 1 ? radius : 1;
-        if (radius > 4) {
-            delete h;
-            return fail(KDE_ERR_UNSUPPORTED, "kde_jbf_create: pre-smoothing radius %d > 4 is not built", radius);
-        }
+        // radii 1..4 have tuned kernels (LDS-resident weight table); larger ones (the OpenCV function takes any kernel
+        // size) run the generic kernel with the table in global memory.  64 bounds the table at 12.5 MB.
+        if (radius > 64) return fail(KDE_ERR_UNSUPPORTED, "kde_jbf_create: pre-smoothing radius %d > 64", radius);
         h->pre_radius = radius;
+        h->pre_grid_cap = presmooth_resident_blocks(radius);
         const float ss = -0.5f / (ss_ * ss_), sc = -0.5f / (sc_ * sc_);
         std::vector<float> lut((size_t)(radius * radius + 1) * 766);
         for (int s2 = 0; s2 <= radius * radius; s2++)
@@ -195,10 +213,8 @@ extern "C" int kde_jbf_create(kde_jbf** out, int width, int height, int max_batc
         if (rc == KDE_OK && hipMemcpy(h->pre_lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
             rc = fail(KDE_ERR_HIP, "kde_jbf_create: lut upload failed");
     }
-    if (rc != KDE_OK) {
-        delete h;
-        return rc;
-    }
+    if (rc != KDE_OK) return rc;
+    guard.h = nullptr;
     *out = h;
     return KDE_OK;
 }
@@ -242,6 +258,7 @@ static int jbf_presmooth(kde_jbf* h, int n, const uint8_t* bgr, uint8_t* dst, hi
     a.src = bgr;
     a.dst = dst;
     a.lut = h->pre_lut.p;
+    a.grid_cap = h->pre_grid_cap;
     return launch_presmooth(a, s);
 }
 
@@ -258,8 +275,7 @@ extern "C" int kde_jbf_process_batch(kde_jbf* h, int n, const float* depth_dev, 
         guide = h->smooth.p;
     }
     KDE_TRY(jbf_filter(h, n, depth_dev, guide, out, s));
-    h->n_last = n;
-    h->last_out = out;
+    if (!filtered_dev) h->n_last = n;       // results in a caller's buffer are the caller's: the host getter never reads them
     return KDE_OK;
 }
 
@@ -285,8 +301,7 @@ extern "C" int kde_jbf_filter_batch(kde_jbf* h, int n, const float* depth_dev, c
     KDE_REQUIRE(n >= 1 && n <= 65535 && (filtered_dev || n <= h->max_batch), "kde_jbf_filter_batch: bad n");
     float* out = filtered_dev ? filtered_dev : h->filtered.p;
     KDE_TRY(jbf_filter(h, n, depth_dev, guide_bgr_dev, out, as_stream(stream)));
-    h->n_last = n;
-    h->last_out = out;
+    if (!filtered_dev) h->n_last = n;
     return KDE_OK;
 }
 
@@ -300,10 +315,12 @@ extern "C" int kde_jbf_filtered_device(kde_jbf* h, float** out)
 extern "C" int kde_jbf_filtered_host(kde_jbf* h, void* stream, const float** out)
 {
     KDE_REQUIRE(h && out, "kde_jbf_filtered_host: null argument");
-    const size_t count = (size_t)h->width * h->height * (h->n_last > 0 ? h->n_last : 1);
+    // Filtered_Host mirrors the object's own Filtered_Device (JointBilateralFilter.cpp:45-49): n_last <= max_batch
+    // frames of it, never a caller-owned output buffer (which may be larger than the pinned buffer, or freed)
+    const int frames = h->n_last > 0 ? (h->n_last < h->max_batch ? h->n_last : h->max_batch) : 1;
+    const size_t count = (size_t)h->width * h->height * frames;
     KDE_TRY(h->filtered_host.ensure((size_t)h->width * h->height * h->max_batch));
-    const float* src = h->last_out ? h->last_out : h->filtered.p;
-    KDE_HIP_TRY(hipMemcpyAsync(h->filtered_host.p, src, count * sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
+    KDE_HIP_TRY(hipMemcpyAsync(h->filtered_host.p, h->filtered.p, count * sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
     KDE_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     *out = h->filtered_host.p;
     return KDE_OK;
@@ -418,8 +435,8 @@ static int dimconv_check(kde_dimconv* h, int n, const void* in, const void* out,
     KDE_REQUIRE(h && in && out, "%s: null argument", who);
     KDE_REQUIRE(h->set, "%s: setCameraParameters was not called", who);
     KDE_REQUIRE(n >= 1 && n <= 65535, "%s: bad frame count %d", who, n);
-    KDE_REQUIRE(aligned16(in) && aligned16(out), "%s: device pointers must be 16-byte aligned", who);
-    KDE_REQUIRE(n == 1 || ((size_t)h->cam.width * h->cam.height) % 4 == 0, "%s: batched call needs width*height %% 4 == 0", who);
+    // any float* / float3* is accepted, as by the reference: pointers that are not 16-byte aligned (or batched frames
+    // whose size is not a multiple of 4) take the scalar kernels of stream_kernels.hip
     return KDE_OK;
 }
 
@@ -477,14 +494,12 @@ extern "C" int kde_buffer2d_destroy(kde_buffer2d* h) { delete h; return KDE_OK; 
 extern "C" int kde_buffer2d_insert_depth(kde_buffer2d* h, const float* depth_dev, void* stream)
 {
     KDE_REQUIRE(h && depth_dev, "kde_buffer2d_insert_depth: null argument");
-    KDE_REQUIRE(aligned16(depth_dev), "kde_buffer2d_insert_depth: device pointer must be 16-byte aligned");
     return launch_buf_insert_depth(h->buf.p, depth_dev, h->buf.n, as_stream(stream));
 }
 
 extern "C" int kde_buffer2d_insert_float2(kde_buffer2d* h, const float* xy_dev, void* stream)
 {
     KDE_REQUIRE(h && xy_dev, "kde_buffer2d_insert_float2: null argument");
-    KDE_REQUIRE((reinterpret_cast<uintptr_t>(xy_dev) & 7u) == 0, "kde_buffer2d_insert_float2: pointer must be 8-byte aligned");
     return launch_buf_insert_float2(h->buf.p, xy_dev, h->width, h->height, as_stream(stream));
 }
 
@@ -498,14 +513,12 @@ extern "C" int kde_buffer2d_insert_weighted(kde_buffer2d* h, const kde_weighted_
 extern "C" int kde_buffer2d_get_depth_map(kde_buffer2d* h, float* out_dev, void* stream)
 {
     KDE_REQUIRE(h && out_dev, "kde_buffer2d_get_depth_map: null argument");
-    KDE_REQUIRE(aligned16(out_dev), "kde_buffer2d_get_depth_map: device pointer must be 16-byte aligned");
     return launch_buf_get(h->buf.p, out_dev, h->buf.n, 0, as_stream(stream));
 }
 
 extern "C" int kde_buffer2d_get_weight_map(kde_buffer2d* h, float* out_dev, void* stream)
 {
     KDE_REQUIRE(h && out_dev, "kde_buffer2d_get_weight_map: null argument");
-    KDE_REQUIRE(aligned16(out_dev), "kde_buffer2d_get_weight_map: device pointer must be 16-byte aligned");
     return launch_buf_get(h->buf.p, out_dev, h->buf.n, 1, as_stream(stream));
 }
 
@@ -513,8 +526,6 @@ extern "C" int kde_buffer2d_update_sequence(kde_buffer2d* h, int n_frames, const
 {
     KDE_REQUIRE(h && depth_dev, "kde_buffer2d_update: null argument");
     KDE_REQUIRE(n_frames >= 1, "kde_buffer2d_update: n_frames must be >= 1");
-    KDE_REQUIRE(aligned16(depth_dev) && (n_frames == 1 || h->buf.n % 2 == 0),
-                "kde_buffer2d_update: pointer must be 16-byte aligned (and width*height even for sequences)");
     return launch_buf_update(h->buf.p, depth_dev, h->buf.n, n_frames, as_stream(stream));
 }
 
@@ -1023,22 +1034,4 @@ extern "C" int kde_spdsr_cluster_nd_device(kde_spdsr* h, float** out)
     KDE_REQUIRE(h && out, "kde_spdsr_cluster_nd_device: null argument");
     *out = h->cluster_nd.p;
     return KDE_OK;
-}
-
-// =====================================================================================================
-// measurement helper
-// =====================================================================================================
-extern "C" int kde_bench_copy(const void* src_dev, void* dst_dev, size_t bytes, void* stream)
-{
-    KDE_REQUIRE(src_dev && dst_dev, "kde_bench_copy: null argument");
-    KDE_REQUIRE(aligned16(src_dev) && aligned16(dst_dev), "kde_bench_copy: pointers must be 16-byte aligned");
-    return launch_copy(src_dev, dst_dev, bytes, as_stream(stream));
-}
-
-extern "C" int kde_test_sqrt_int24(uint32_t first, uint32_t n, float* out_dev, void* stream)
-{
-    KDE_REQUIRE(out_dev, "kde_test_sqrt_int24: null argument");
-    KDE_REQUIRE((uint64_t)first + n <= (1ull << 24), "kde_test_sqrt_int24: arguments must stay below 2^24");
-    if (n == 0) return KDE_OK;
-    return launch_sqrt_int24_probe(first, n, out_dev, as_stream(stream));
 }

@@ -1,0 +1,21 @@
+// kde_device_math.h — small device functions shared by the product kernels and the test-hook library
+// (tools/hooks/test_hooks.hip), so that a test can call exactly the code a kernel runs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace kde {
+
+// sqrtf() of an integer-valued float in [0, 2^24): v_rsq_f32 estimate, one Heron step on the exact fma residual.
+// The library sqrtf() spends 14 instructions (denormal scaling, two +-1 ulp probes, class test) to be correctly
+// rounded for every float; on this domain 6 are enough -- tests/test_gpu_dasp_ers.py checks ALL 2^24 arguments
+// against sqrtf bit for bit (px*px + py*py of pixel offsets, the only argument K7 has, is such an integer).
+__device__ __forceinline__ float sqrt_int24(float x)
+{
+    const float y = __builtin_amdgcn_rsqf(x);          // 1/sqrt(x), 1 ulp; +inf for x == 0
+    const float r = x * y;
+    const float e = __builtin_fmaf(-r, r, x);          // exact residual x - r^2
+    const float r1 = __builtin_fmaf(e, 0.5f * y, r);
+    return x == 0.0f ? 0.0f : r1;
+}
+
+}  // namespace kde

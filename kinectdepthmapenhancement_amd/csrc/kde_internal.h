@@ -136,8 +136,10 @@ struct PresmoothLaunch {
     const uint8_t* src;        // [n][H][W][3]
     uint8_t* dst;
     const float* lut;          // device, (radius^2+1) x 766 weights
+    long long grid_cap;        // persistent-grid size for the tuned kernels (presmooth_resident_blocks at handle creation)
 };
 int launch_presmooth(const PresmoothLaunch& a, hipStream_t s);
+long long presmooth_resident_blocks(int radius);   // on the current device; 0 for radii served by the generic kernel
 
 struct MrfLaunch {
     int width, height, n, window;
@@ -163,12 +165,10 @@ int launch_buf_insert_depth(kde_weighted_d* buf, const float* d, size_t n, hipSt
 int launch_buf_insert_float2(kde_weighted_d* buf, const float* xy, int width, int height, hipStream_t s);
 int launch_buf_get(const kde_weighted_d* buf, float* out, size_t n, int which, hipStream_t s);
 int launch_buf_update(kde_weighted_d* buf, const float* d, size_t n, int n_frames, hipStream_t s);
-int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
 
 struct DaspGeom {
     int width, height, rows, cols, wx, wy;
 };
-int launch_sqrt_int24_probe(uint32_t first, uint32_t n, float* out, hipStream_t s);
 int launch_dasp_sample(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
                        kde_float3* centers, hipStream_t s);
 int launch_dasp_calc_ld(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld,

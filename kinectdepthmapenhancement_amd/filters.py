@@ -434,9 +434,3 @@ class SPDepthSuperResolution(_PipelineBase):
 
     def getClusterND_Device(self):
         return self._get("cluster_nd_device", (self.sp_rows * self.sp_cols, 4), torch.float32)
-
-
-def hbm_copy(src: torch.Tensor, dst: torch.Tensor) -> None:
-    """float4 streaming copy used for the empirical HBM ceiling in bench.py."""
-    nbytes = src.numel() * src.element_size()
-    check(lib().kde_bench_copy(src.data_ptr(), dst.data_ptr(), nbytes, _stream()))

@@ -329,11 +329,15 @@ def test_chain_is_hip_graph_capturable(torch_cuda, F, oracle, synth, frame):
 def test_k7_integer_sqrt_is_sqrtf_on_its_whole_domain(torch_cuda):
     """calculateLD's spatial distance is sqrtf(px*px + py*py) of integer pixel offsets; the kernels compute it with a
     6-instruction square root that is only claimed exact for integer arguments below 2^24 -- all of them are checked."""
-    from kinectdepthmapenhancement_amd import _native
-    lib = _native.lib()
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("kde_hooks", os.path.join(ROOT, "tools", "hooks", "hooks.py"))
+    hooks = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hooks)          # tools/hooks/libkde_hooks.so compiles the SAME kde_device_math.h the kernels use
     n = 1 << 24
     out = torch_cuda.empty(n, dtype=torch_cuda.float32, device="cuda")
-    _native.check(lib.kde_test_sqrt_int24(0, n, out.data_ptr(), torch_cuda.cuda.current_stream().cuda_stream))
+    assert hooks.lib().kde_test_sqrt_int24(0, n, out.data_ptr(), torch_cuda.cuda.current_stream().cuda_stream) == 0
     got = out.cpu().numpy()
     ref = np.sqrt(np.arange(n, dtype=np.float32))        # IEEE correctly rounded
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), int((got != ref).sum())

@@ -48,6 +48,38 @@ def test_presmooth_other_kernel_sizes(torch_cuda, F, oracle, frame, ksize, sc, s
     assert np.array_equal(host(out)[0], oracle.cv_bilateral(bgr, ksize, sc, ss))
 
 
+@pytest.mark.parametrize("ksize,sc,ss", [(11, 30.0, 30.0), (13, 20.0, 4.0), (0, 30.0, 4.0), (31, 40.0, 9.0)])
+def test_presmooth_radius_above_four_uses_the_generic_kernel(torch_cuda, F, oracle, frame, ksize, sc, ss):
+    """cv::gpu::bilateralFilter takes any kernel size (ksize 0 -> radius round(1.5 sigma_s)); radii > 4 have no tuned
+    kernel and run the generic one: same bytes as the oracle, including ragged sizes and batches"""
+    for size, seed in (((96, 64), 6), ((33, 9), 4)):
+        w, h = size
+        bgr = np.stack([frame(seed, w, h)[0], frame(seed + 1, w, h)[0]])
+        jbf = F.JointBilateralFilter(w, h, params(F, pk=ksize, pc=sc, ps=ss), max_batch=2)
+        out = torch_cuda.empty((2, h, w, 3), dtype=torch_cuda.uint8, device="cuda")
+        jbf.presmooth_batch(dev(torch_cuda, bgr), out)
+        for i in range(2):
+            assert np.array_equal(host(out)[i], oracle.cv_bilateral(bgr[i], ksize, sc, ss))
+
+
+def test_filtered_host_never_reads_a_callers_buffer(torch_cuda, F, oracle, synth):
+    """filter_batch(n > max_batch, out=caller buffer) followed by getFiltered_Host() used to copy n frames out
+    of the caller's pointer into a pinned buffer sized for max_batch.  The host getter mirrors the object's own
+    Filtered_Device only."""
+    bgr, depth = synth.make_batch(60, 4, 64, 48)
+    jbf = F.JointBilateralFilter(64, 48, params(F, pre=0), max_batch=1)
+    jbf.filter_batch(dev(torch_cuda, depth[:1]), dev(torch_cuda, bgr[:1]), jbf.getFiltered_Device()[None])
+    own = jbf.getFiltered_Host().copy()
+    big = torch_cuda.empty((4, 48, 64), dtype=torch_cuda.float32, device="cuda")
+    jbf.filter_batch(dev(torch_cuda, depth), dev(torch_cuda, bgr), big)           # n = 4 > max_batch = 1, caller-owned output
+    del big
+    torch_cuda.cuda.empty_cache()
+    again = jbf.getFiltered_Host()
+    assert again.shape == (48, 64) and np.array_equal(again, own)                # still the object's own frame 0
+    ref = oracle.jbf_kernel(depth[0], bgr[0])
+    assert_depth_close(own, ref, RTOL, what="filtered host")
+
+
 @pytest.mark.parametrize("cfg", [
     dict(w=5, ss=70.0, cs=50.0, ds=20.0),      # the reference's compile-time constants
     dict(w=11, ss=3.0, cs=7.65, ds=20.0),      # BASELINE "radius=5 sigma_s=3 sigma_r=0.03"

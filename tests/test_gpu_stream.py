@@ -67,11 +67,7 @@ def test_buffer2d_bit_exact(torch_cuda, F, oracle, synth, size):
         ob.update(seq[i])
     assert np.array_equal(host(gb.getDepthMap(out)), ob.depth_map())
     assert np.array_equal(host(gb.getWeightMap(out)), ob.weight_map())
-    if (w * h) % 2 == 0:
-        gb.updateData(dev(t, seq[3:6]))          # fused multi-frame update == three single updates
-    else:
-        for i in range(3, 6):
-            gb.updateData(dev(t, seq[i]))
+    gb.updateData(dev(t, seq[3:6]))              # fused multi-frame update == three single updates (any W*H)
     for i in range(3, 6):
         ob.update(seq[i])
     assert np.array_equal(host(gb.getDepthMap(out)), ob.depth_map())
@@ -90,3 +86,93 @@ def test_buffer2d_bit_exact(torch_cuda, F, oracle, synth, size):
     other = F.Buffer2D(w, h)
     other.insertWeighted(gb.getRawPointer())
     assert np.array_equal(host(other.getRawPointer()), host(gb.getRawPointer()))
+
+
+def _offset(t, a, floats=1):
+    """device copy of `a` whose data pointer sits `floats` * 4 bytes past a 256-byte aligned allocation"""
+    flat = t.empty(a.size + floats, dtype=t.float32, device="cuda")
+    view = flat[floats:].view(a.shape)
+    view.copy_(t.from_numpy(np.ascontiguousarray(a)))
+    assert view.data_ptr() % 16 == (4 * floats) % 16 and view.is_contiguous()
+    return view
+
+
+@pytest.mark.parametrize("size", [(33, 9), (31, 7), (70, 50), (641, 3)])
+@pytest.mark.parametrize("off", [1, 2, 3])
+def test_dimension_convertor_takes_any_pointer_and_any_size(torch_cuda, F, oracle, synth, size, off):
+    """the reference takes any float* / float3* and any frame size: pointers 4 / 8 / 12 bytes off a 16-byte boundary and
+    batches of frames whose size is not a multiple of 4 must work (scalar kernels), bit-exact like the vector path"""
+    w, h = size
+    t = torch_cuda
+    rng = np.random.default_rng(w * 131 + off)
+    depth = (rng.random((3, h, w), np.float32) * 4000).astype(np.float32)
+    depth[rng.random((3, h, w)) < 0.1] = 0
+    K = synth.intrinsics(w, h)
+    conv = F.DimensionConvertor()
+    conv.setCameraParameters(K, w, h)
+    d = _offset(t, depth, off)
+    pts = _offset(t, np.zeros((3, h, w, 3), np.float32), off)
+    conv.projectiveToReal(d, pts)
+    ref = [oracle.p2r_depth(depth[i], K) for i in range(3)]
+    for i in range(3):
+        assert np.array_equal(host(pts[i]), pts_as_f32(ref[i]))
+    out = _offset(t, np.zeros((3, h, w, 3), np.float32), (off + 1) % 4 or 1)
+    conv.realToProjective(pts, out)
+    for i in range(3):
+        assert np.array_equal(host(out[i]), pts_as_f32(oracle.r2p(ref[i], K)))
+    back = _offset(t, np.zeros((3, h, w, 3), np.float32), off)
+    conv.projectiveToReal(out, back)
+    for i in range(3):
+        assert np.array_equal(host(back[i]), pts_as_f32(oracle.p2r_points(oracle.r2p(ref[i], K), K)), equal_nan=True)
+    conv.projectiveToRealInterp(d, back)
+    for i in range(3):
+        assert np.array_equal(host(back[i]), pts_as_f32(oracle.p2r_interp(depth[i], K)))
+    # aligned pointers, single odd-sized frame: vector path + its scalar tail
+    one = t.empty((h, w, 3), dtype=t.float32, device="cuda")
+    conv.projectiveToReal(dev(t, depth[0]), one)
+    assert np.array_equal(host(one), pts_as_f32(ref[0]))
+
+
+@pytest.mark.parametrize("size", [(33, 9), (31, 7), (70, 50)])
+@pytest.mark.parametrize("off", [0, 1, 3])
+def test_buffer2d_takes_any_pointer_and_any_size(torch_cuda, F, oracle, size, off):
+    w, h = size
+    t = torch_cuda
+    rng = np.random.default_rng(w + 7 * off)
+    base = (800 + 2000 * rng.random((h, w))).astype(np.float32)
+    seq = np.stack([base + rng.normal(0, 2.0, (h, w)).astype(np.float32) for _ in range(5)]).astype(np.float32)
+    seq[rng.random(seq.shape) < 0.1] = 0
+    gb, ob = F.Buffer2D(w, h), oracle.Buffer2D(w, h)
+    gb.updateData(_offset(t, seq[0], off) if off else dev(t, seq[0]))
+    ob.update(seq[0])
+    gb.updateData(_offset(t, seq[1:5], off) if off else dev(t, seq[1:5]))     # fused sequence, odd W*H, any alignment
+    for i in range(1, 5):
+        ob.update(seq[i])
+    outd = _offset(t, np.zeros((h, w), np.float32), off) if off else t.empty((h, w), dtype=t.float32, device="cuda")
+    assert np.array_equal(host(gb.getDepthMap(outd)), ob.depth_map())
+    assert np.array_equal(host(gb.getWeightMap(outd)), ob.weight_map())
+    assert ob.weight_map().max() >= 4
+    gb.insertData(_offset(t, seq[2], off) if off else dev(t, seq[2]))
+    ob.insert_depth(seq[2])
+    assert np.array_equal(host(gb.getRawPointer()), ob.buf.view(np.float32).reshape(h, w, 2))
+    xy = np.stack([seq[3], seq[4]], -1)
+    gb.insertData(_offset(t, xy, off) if off else dev(t, xy))
+    ob.insert_float2(xy)
+    assert np.array_equal(host(gb.getRawPointer()), ob.buf.view(np.float32).reshape(h, w, 2))
+
+
+def test_buffer2d_fused_sequence_full_size(torch_cuda, F, oracle, synth):
+    """32 x 640x480 frames fused into one read-modify-write (row f4) == 32 single updates, bit for bit"""
+    t = torch_cuda
+    w, h, n = 640, 480, 32
+    _, d0, truth = synth.make_frame(90, w, h, clean=True)
+    rng = np.random.default_rng(9)
+    seq = (truth[None] + rng.normal(0, 3.0, (n, h, w))).astype(np.float32) * (truth[None] > 0)
+    seq[rng.random(seq.shape) < 0.05] = 0
+    seq = np.ascontiguousarray(seq.astype(np.float32))
+    gb, ob = F.Buffer2D(w, h), oracle.Buffer2D(w, h)
+    gb.updateData(dev(t, seq))
+    for i in range(n):
+        ob.update(seq[i])
+    assert np.array_equal(host(gb.getRawPointer()), ob.buf.view(np.float32).reshape(h, w, 2))
+    assert ob.weight_map().max() >= 20

@@ -28,13 +28,14 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int kUnroll = 32;    // instructions (or instruction groups) per loop trip
 
-enum Kind { FMA, PK_FMA, PK_MUL, PK_ADD, EXP, RCP, DOT4, LSHL_ADD, ADD_U32, CNDMASK, MAX_F32,
+enum Kind { FMA, PK_FMA, PK_MUL, PK_ADD, EXP, RCP, DOT4, LSHL_ADD, ADD_U32, CNDMASK, CNDMASK_SGPR, CMP_CNDMASK, MUL_F32, CVT_I32, MAX_F32,
             MIX_EXP_4PK, MIX_EXP_2PK, MIX_EXP_1PK, MIX_DOT_LSHL_PK, MIX_K1_PASS1, NKINDS };
 const char* kNames[NKINDS] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_exp_f32", "v_rcp_f32",
-                              "v_dot4_u32_u8", "v_lshl_add_u32", "v_add_u32", "v_cndmask_b32", "v_max_f32",
+                              "v_dot4_u32_u8", "v_lshl_add_u32", "v_add_u32", "v_cndmask_b32 (vcc)", "v_cndmask_b32_e64 (sgpr pair)",
+                              "v_cmp_lt_f32 + v_cndmask_b32 (per instruction)", "v_mul_f32", "v_cvt_i32_f32", "v_max_f32",
                               "1 v_exp_f32 + 4 v_pk_fma_f32", "1 v_exp_f32 + 2 v_pk_fma_f32", "1 v_exp_f32 + 1 v_pk_fma_f32",
                               "1 v_dot4 + 1 v_lshl_add + 1 v_pk_fma", "K1 pass-1 unit: 2 dot4 + 2 lshl_add + 2 exp + 6 pk"};
-const int kPerGroup[NKINDS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 5, 3, 2, 3, 12};
+const int kPerGroup[NKINDS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 5, 3, 2, 3, 12};
 
 template <int KIND>
 __global__ void bench(uint64_t* ticks, float* sink, float seed, int reps)
@@ -70,6 +71,13 @@ __global__ void bench(uint64_t* ticks, float* sink, float seed, int reps)
             if (KIND == ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
             if (KIND == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c0));
             if (KIND == MAX_F32) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
+            if (KIND == CNDMASK_SGPR) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a[i]) : "v"(c0));
+            if (KIND == CMP_CNDMASK) {
+                asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(c0) : "vcc");
+                asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[(i + 1) & 7]) : "v"(c0) : "vcc");
+            }
+            if (KIND == MUL_F32) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
+            if (KIND == CVT_I32) asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(u[i]) : "v"(a[i]));
             if (KIND == MIX_EXP_4PK) {
                 asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
                 asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));
@@ -190,6 +198,10 @@ int main()
     if (run_kind<LSHL_ADD>(cus, d_ticks, d_sink, h)) return 1;
     if (run_kind<ADD_U32>(cus, d_ticks, d_sink, h)) return 1;
     if (run_kind<CNDMASK>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<CNDMASK_SGPR>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<CMP_CNDMASK>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<MUL_F32>(cus, d_ticks, d_sink, h)) return 1;
+    if (run_kind<CVT_I32>(cus, d_ticks, d_sink, h)) return 1;
     if (run_kind<MAX_F32>(cus, d_ticks, d_sink, h)) return 1;
     if (run_kind<MIX_EXP_4PK>(cus, d_ticks, d_sink, h)) return 1;
     if (run_kind<MIX_EXP_2PK>(cus, d_ticks, d_sink, h)) return 1;
