@@ -1,0 +1,300 @@
+// shard_replay.cpp — a batch of independent RGB-D frames sharded over the GPUs of one node by a C++ host
+// (BASELINE config 4): ONE process, one host thread per visible device.  Each thread
+//   * binds its device (kde_set_device) and owns its stream, its kde_jbf handle and its shard's buffers,
+//   * takes the filter parameter block {window, sigmas, pre-smoothing, spatial table} from rank 0 through ONE
+//     ncclBroadcast (RCCL over xGMI) and checks its own host-computed table against rank 0's,
+//   * filters its contiguous block of ceil(N / G) frames with kde_jbf_process_batch; there is no data-path
+//     collective (frames are independent units) and outputs stay on the owning GPU.
+// The reference uploads to a single device (main.cpp:160-163); this is the multi-device host a maintainer would
+// write on the same C ABI (include/kde_hip.h).
+//
+// usage: shard_replay [--frames N] [--width W] [--height H] [--window 11] [--steps K] [--devices G] [--verify]
+//   --verify: the same N frames are also filtered on device 0 alone, as ONE block and as TWO half blocks, and the
+//             per-frame checksums of all three runs must be identical (partition independence, bit for bit).
+// prints one JSON line: per-device times, aggregate Mpixels/s, checksum, "params_broadcast": "rccl" | "single-device".
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../include/kde_hip.h"
+
+#define HIP_OK(x)                                                                                  \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            std::fprintf(stderr, "%s: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            std::exit(2);                                                                          \
+        }                                                                                          \
+    } while (0)
+#define KDE_OK_OR_DIE(x)                                                                           \
+    do {                                                                                           \
+        int rc_ = (x);                                                                             \
+        if (rc_ != KDE_OK) {                                                                       \
+            std::fprintf(stderr, "%s: %s (%s:%d)\n", #x, kde_last_error_string(), __FILE__, __LINE__); \
+            std::exit(2);                                                                          \
+        }                                                                                          \
+    } while (0)
+#define NCCL_OK(x)                                                                                 \
+    do {                                                                                           \
+        ncclResult_t r_ = (x);                                                                     \
+        if (r_ != ncclSuccess) {                                                                   \
+            std::fprintf(stderr, "%s: %s (%s:%d)\n", #x, ncclGetErrorString(r_), __FILE__, __LINE__); \
+            std::exit(2);                                                                          \
+        }                                                                                          \
+    } while (0)
+
+namespace {
+
+struct Options {
+    int frames = 64, width = 640, height = 480, window = 11, steps = 5, devices = 0;
+    float spatial_sigma = 3.0f, color_sigma = 7.65f, depth_sigma = 20.0f;
+    bool verify = false;
+};
+
+// deterministic synthetic frame (seed = global frame index): a smooth ramp with rectangles, noise and holes.
+// Not the Python generator of the tests -- this program only needs frames that differ and exercise every path.
+uint32_t lcg(uint32_t& s) { return s = s * 1664525u + 1013904223u; }
+
+void make_frame(int seed, int W, int H, std::vector<uint8_t>& bgr, std::vector<float>& depth)
+{
+    bgr.resize((size_t)W * H * 3);
+    depth.resize((size_t)W * H);
+    uint32_t s = 0x9E3779B9u * (uint32_t)(seed + 1);
+    int rx[6], ry[6], rw[6], rh[6], rc[6];
+    float rz[6];
+    for (int k = 0; k < 6; k++) {
+        rw[k] = W / 8 + (int)(lcg(s) % (unsigned)(W / 3));
+        rh[k] = H / 8 + (int)(lcg(s) % (unsigned)(H / 3));
+        rx[k] = (int)(lcg(s) % (unsigned)(W - rw[k]));
+        ry[k] = (int)(lcg(s) % (unsigned)(H - rh[k]));
+        rc[k] = (int)(lcg(s) & 0xffffff);
+        rz[k] = 800.0f + (float)(lcg(s) % 3200u);
+    }
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            float z = 3000.0f + 0.4f * x - 0.2f * y;
+            int c = ((x * 255 / W) << 16) | ((y * 255 / H) << 8) | 0x40;
+            for (int k = 0; k < 6; k++)
+                if (x >= rx[k] && x < rx[k] + rw[k] && y >= ry[k] && y < ry[k] + rh[k]) {
+                    z = rz[k] + 0.1f * (x - rx[k]);
+                    c = rc[k];
+                }
+            const uint32_t r = lcg(s);
+            z += ((float)(r & 0xff) - 127.5f) * 0.02f;
+            if ((r >> 8) % 100u == 0) z = 0.0f;       // 1 % holes
+            const size_t q = (size_t)y * W + x;
+            depth[q] = z;
+            for (int ch = 0; ch < 3; ch++) {
+                int v = ((c >> (8 * ch)) & 0xff) + (int)((r >> (16 + 3 * ch)) & 7) - 4;
+                bgr[q * 3 + ch] = (uint8_t)std::min(255, std::max(0, v));
+            }
+        }
+}
+
+// FNV-1a over the raw bytes of one frame: equal iff the frames are bit-identical (up to hash collisions)
+uint64_t fnv(const float* p, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n * 4; i++) {
+        h ^= b[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+constexpr int kBlockLen = 8 + 31 * 31;     // params + the largest spatial table
+
+void pack_params(const kde_jbf_params& p, const std::vector<float>& table, float* blk)
+{
+    std::memset(blk, 0, sizeof(float) * kBlockLen);
+    blk[0] = (float)p.window_size; blk[1] = p.spatial_sigma; blk[2] = p.color_sigma; blk[3] = p.depth_sigma;
+    blk[4] = (float)p.presmooth; blk[5] = (float)p.presmooth_kernel_size; blk[6] = p.presmooth_sigma_color;
+    blk[7] = p.presmooth_sigma_spatial;
+    std::memcpy(blk + 8, table.data(), table.size() * sizeof(float));
+}
+
+kde_jbf_params unpack_params(const float* blk)
+{
+    kde_jbf_params p;
+    p.window_size = (int)blk[0]; p.spatial_sigma = blk[1]; p.color_sigma = blk[2]; p.depth_sigma = blk[3];
+    p.presmooth = (int)blk[4]; p.presmooth_kernel_size = (int)blk[5]; p.presmooth_sigma_color = blk[6];
+    p.presmooth_sigma_spatial = blk[7];
+    return p;
+}
+
+struct ShardResult {
+    double ms_per_step = 0.0;
+    std::vector<uint64_t> frame_hash;       // one per frame of the shard
+    bool table_matches_rank0 = true;
+};
+
+// filters frames [first, first + count) on `device`; if comm != nullptr the parameter block comes from rank 0's broadcast
+ShardResult run_shard(const Options& o, int device, int rank, int first, int count, ncclComm_t comm, const kde_jbf_params& root_params)
+{
+    ShardResult res;
+    KDE_OK_OR_DIE(kde_set_device(device));
+    hipStream_t stream;
+    HIP_OK(hipStreamCreate(&stream));
+    const size_t px = (size_t)o.width * o.height;
+
+    // ---- parameter block: rank 0 decides, everyone receives the same bytes over RCCL ----
+    float* blk_dev = nullptr;
+    HIP_OK(hipMalloc(&blk_dev, sizeof(float) * kBlockLen));
+    std::vector<float> blk(kBlockLen, 0.0f);
+    if (rank == 0) {
+        kde_jbf* probe = nullptr;
+        KDE_OK_OR_DIE(kde_jbf_create(&probe, 8, 8, 1, &root_params));
+        std::vector<float> table((size_t)root_params.window_size * root_params.window_size);
+        KDE_OK_OR_DIE(kde_jbf_spatial_table(probe, table.data(), (int)table.size()));
+        KDE_OK_OR_DIE(kde_jbf_destroy(probe));
+        pack_params(root_params, table, blk.data());
+        HIP_OK(hipMemcpyAsync(blk_dev, blk.data(), sizeof(float) * kBlockLen, hipMemcpyHostToDevice, stream));
+    }
+    if (comm) NCCL_OK(ncclBroadcast(blk_dev, blk_dev, kBlockLen, ncclFloat, 0, comm, stream));
+    HIP_OK(hipMemcpyAsync(blk.data(), blk_dev, sizeof(float) * kBlockLen, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    const kde_jbf_params p = (comm || rank == 0) ? unpack_params(blk.data()) : root_params;
+
+    kde_jbf* jbf = nullptr;
+    KDE_OK_OR_DIE(kde_jbf_create(&jbf, o.width, o.height, std::max(count, 1), &p));
+    {   // every rank provably filters with rank 0's table
+        std::vector<float> mine((size_t)p.window_size * p.window_size);
+        KDE_OK_OR_DIE(kde_jbf_spatial_table(jbf, mine.data(), (int)mine.size()));
+        if (comm || rank == 0) res.table_matches_rank0 = std::memcmp(mine.data(), blk.data() + 8, mine.size() * sizeof(float)) == 0;
+    }
+    if (count > 0) {
+        // ---- this shard's frames, resident in this device's HBM ----
+        float* depth_dev = nullptr;
+        uint8_t* bgr_dev = nullptr;
+        float* out_dev = nullptr;
+        HIP_OK(hipMalloc(&depth_dev, px * count * sizeof(float)));
+        HIP_OK(hipMalloc(&bgr_dev, px * count * 3));
+        HIP_OK(hipMalloc(&out_dev, px * count * sizeof(float)));
+        std::vector<uint8_t> bgr;
+        std::vector<float> depth;
+        for (int f = 0; f < count; f++) {
+            make_frame(first + f, o.width, o.height, bgr, depth);
+            HIP_OK(hipMemcpy(depth_dev + px * f, depth.data(), px * sizeof(float), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(bgr_dev + px * 3 * f, bgr.data(), px * 3, hipMemcpyHostToDevice));
+        }
+        KDE_OK_OR_DIE(kde_jbf_process_batch(jbf, count, depth_dev, bgr_dev, out_dev, stream));   // warm-up
+        hipEvent_t e0, e1;
+        HIP_OK(hipEventCreate(&e0));
+        HIP_OK(hipEventCreate(&e1));
+        HIP_OK(hipEventRecord(e0, stream));
+        for (int k = 0; k < o.steps; k++) KDE_OK_OR_DIE(kde_jbf_process_batch(jbf, count, depth_dev, bgr_dev, out_dev, stream));
+        HIP_OK(hipEventRecord(e1, stream));
+        HIP_OK(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        res.ms_per_step = ms / o.steps;
+        std::vector<float> out(px);
+        for (int f = 0; f < count; f++) {
+            HIP_OK(hipMemcpy(out.data(), out_dev + px * f, px * sizeof(float), hipMemcpyDeviceToHost));
+            res.frame_hash.push_back(fnv(out.data(), px));
+        }
+        HIP_OK(hipFree(depth_dev));
+        HIP_OK(hipFree(bgr_dev));
+        HIP_OK(hipFree(out_dev));
+    }
+    KDE_OK_OR_DIE(kde_jbf_destroy(jbf));
+    HIP_OK(hipFree(blk_dev));
+    HIP_OK(hipStreamDestroy(stream));
+    return res;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    Options o;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
+        if (a == "--frames") o.frames = std::atoi(next());
+        else if (a == "--width") o.width = std::atoi(next());
+        else if (a == "--height") o.height = std::atoi(next());
+        else if (a == "--window") o.window = std::atoi(next());
+        else if (a == "--steps") o.steps = std::atoi(next());
+        else if (a == "--devices") o.devices = std::atoi(next());
+        else if (a == "--verify") o.verify = true;
+        else {
+            std::fprintf(stderr, "unknown argument %s\n", a.c_str());
+            return 2;
+        }
+    }
+    int visible = 0;
+    KDE_OK_OR_DIE(kde_device_count(&visible));
+    const int G = o.devices > 0 ? std::min(o.devices, visible) : visible;
+    if (G < 1 || o.frames < 1 || o.steps < 1) {
+        std::fprintf(stderr, "need at least one device, frame and step\n");
+        return 2;
+    }
+    kde_jbf_params p;
+    KDE_OK_OR_DIE(kde_jbf_default_params(&p));
+    p.window_size = o.window;
+    p.spatial_sigma = o.spatial_sigma;
+    p.color_sigma = o.color_sigma;
+    p.depth_sigma = o.depth_sigma;
+
+    // one RCCL communicator per device (single process, one thread per device)
+    std::vector<ncclComm_t> comms(G, nullptr);
+    std::vector<int> devs(G);
+    for (int d = 0; d < G; d++) devs[d] = d;
+    NCCL_OK(ncclCommInitAll(comms.data(), G, devs.data()));
+
+    // contiguous blocks of ceil(N / G) frames
+    const int per = (o.frames + G - 1) / G;
+    std::vector<ShardResult> results(G);
+    std::vector<std::thread> threads;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int d = 0; d < G; d++)
+        threads.emplace_back([&, d]() {
+            const int first = std::min(d * per, o.frames), count = std::min(per, o.frames - first);
+            results[d] = run_shard(o, d, d, first, count, comms[d], p);
+        });
+    for (auto& t : threads) t.join();
+    const double wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int d = 0; d < G; d++) NCCL_OK(ncclCommDestroy(comms[d]));
+
+    double slowest = 0.0;
+    bool tables_ok = true;
+    std::vector<uint64_t> hashes;
+    for (int d = 0; d < G; d++) {
+        slowest = std::max(slowest, results[d].ms_per_step);
+        tables_ok = tables_ok && results[d].table_matches_rank0;
+        hashes.insert(hashes.end(), results[d].frame_hash.begin(), results[d].frame_hash.end());
+    }
+    uint64_t all = 1469598103934665603ull;
+    for (uint64_t h : hashes) all = (all ^ h) * 1099511628211ull;
+
+    bool verified = true;
+    if (o.verify) {
+        // the same frames on device 0 alone: as one block, and as two half blocks -> per-frame hashes must coincide
+        ShardResult one = run_shard(o, 0, 0, 0, o.frames, nullptr, p);
+        const int half = o.frames / 2;
+        ShardResult a = run_shard(o, 0, 0, 0, half, nullptr, p), b = run_shard(o, 0, 0, half, o.frames - half, nullptr, p);
+        std::vector<uint64_t> two(a.frame_hash);
+        two.insert(two.end(), b.frame_hash.begin(), b.frame_hash.end());
+        verified = one.frame_hash == hashes && two == hashes;
+    }
+    const double mpix = (double)o.frames * o.width * o.height / (slowest * 1e-3) / 1e6;
+    std::printf("{\"devices\": %d, \"frames\": %d, \"frames_per_device\": %d, \"width\": %d, \"height\": %d, \"window\": %d, "
+                "\"ms_per_step_slowest_device\": %.4f, \"mpixels_per_s\": %.1f, \"params_broadcast\": \"%s\", "
+                "\"tables_match_rank0\": %s, \"checksum\": \"%016llx\", \"verified\": %s, \"wall_s\": %.2f}\n",
+                G, o.frames, per, o.width, o.height, o.window, slowest, mpix, "rccl ncclBroadcast", tables_ok ? "true" : "false",
+                (unsigned long long)all, o.verify ? (verified ? "true" : "false") : "null", wall_s);
+    return (tables_ok && verified) ? 0 : 1;
+}

@@ -19,43 +19,6 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
-// ---- host math shared by several objects ------------------------------------------------------------
-float exp_zero_threshold()
-{
-    // exp(-x) rounds to 0 in binary32 iff exp(-x) < 2^-150 iff x > 150 ln 2
-    const double t = 150.0 * 0.693147180559945309417232121458;
-    float f = (float)t;
-    while ((double)f <= t) f = std::nextafterf(f, INFINITY);
-    while ((double)std::nextafterf(f, 0.0f) > t) f = std::nextafterf(f, 0.0f);
-    return f;
-}
-
-void spatial_table(int window, float sigma, float* table)
-{
-    // JointBilateralFilter.cpp:31-40 (powf(x, 2.0f) written x*x)
-    for (int i = 0; i < window; i++)
-        for (int j = 0; j < window; j++) {
-            const float fx = (float)(j - window / 2), fy = (float)(i - window / 2);
-            const float dis_x = fx * fx, dis_y = fy * fy;
-            table[i * window + j] = expf(-(dis_x + dis_y) / (2.0f * (sigma * sigma)));
-        }
-}
-
-// smallest non-negative float q with q / den >= thr (float division); +inf if none
-static float smallest_q_reaching(float den, float thr)
-{
-    if (!(den > 0.0f)) return 0.0f;
-    uint32_t lo = 0, hi = 0x7f800000u;   // bit patterns of +0 .. +inf are ordered like the values
-    auto val = [](uint32_t b) { float f; memcpy(&f, &b, 4); return f; };
-    if (!(val(hi) / den >= thr)) return INFINITY;
-    while (lo < hi) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if (val(mid) / den >= thr) hi = mid;
-        else lo = mid + 1;
-    }
-    return val(lo);
-}
-
 }  // namespace kde
 
 using namespace kde;
@@ -180,15 +143,7 @@ static int jbf_create_impl(kde_jbf** out, int width, int height, int max_batch, 
     h->color_den = 2 * (p.color_sigma * p.color_sigma);
     h->depth_den = 2.0f * (p.depth_sigma * p.depth_sigma);
     h->cd_skip = INT_MAX;
-    if (p.color_sigma != 0.0f) {
-        int lo = 0, hi = 195076;   // 3*255^2 + 1
-        while (lo < hi) {
-            const int mid = (lo + hi) / 2;
-            if ((float)mid / h->color_den >= xz) hi = mid;
-            else lo = mid + 1;
-        }
-        h->cd_skip = lo;   // 195076 = never reached
-    }
+    if (p.color_sigma != 0.0f) h->cd_skip = smallest_cd_reaching(h->color_den, xz);   // 195076 = never reached
     h->d2_skip = p.depth_sigma != 0.0f ? smallest_q_reaching(h->depth_den, xz) : INFINITY;
     // K0 table: weight(space2, n1) = expf(space2*ss + n1^2*sc), the expression of OpenCV's kernel
     if (rc == KDE_OK && p.presmooth) {

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/kde_hip.h"
+#include "kde_host_math.h"   // exp_zero_threshold, spatial_table, smallest_*_reaching (pure C++)
 
 namespace kde {
 
@@ -97,12 +98,6 @@ struct PinnedBuf {
     PinnedBuf(const PinnedBuf&) = delete;
     PinnedBuf& operator=(const PinnedBuf&) = delete;
 };
-
-// ---- exp() underflow thresholds (the reference's "skip the factor if it is exactly 0" rule) --
-// smallest float x with exp(-x) rounding to 0 in IEEE binary32 (round to nearest): x > 150*ln2
-float exp_zero_threshold();
-// spatial table of calcSpatialFilter (JointBilateralFilter.cpp:31-40 / EdgeRefinedSuperpixel.cpp:46-55)
-void spatial_table(int window, float sigma, float* table);
 
 // ---- launchers implemented in the .hip translation units ------------------------------------
 struct JbfLaunch {
