@@ -19,13 +19,18 @@ namespace {
 // ---- K5 init_LD (.cu:3-14): folded into the first calculateLD (calc_ld_kernel<.., FIRST>) --------------
 
 // ---- K6 sampleInitialClusters<16> (.cu:16-165) ---------------------------------------------------
-// one 64-lane wavefront = 4 clusters x 16 candidates
-__global__ __launch_bounds__(64) void sample_clusters_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
-                                                            const kde_float3* __restrict__ pts,
-                                                            kde_superpixel* __restrict__ mean,
-                                                            kde_float3* __restrict__ centers)
+// A workgroup of four wavefronts serves 4 clusters x 16 candidates (one candidate per lane, as the reference's 16-thread
+// blocks).  The 121 gradient terms of a candidate are independent; only their SUM has an order (yy outer, xx inner)
+// that the float result -- and with it the argmin's ties -- depends on.  So the four wavefronts each evaluate a quarter
+// of the terms into LDS, and wavefront 0 then adds them up in the reference's order: the kernel is a latency chain on a
+// nearly empty GPU (75 workgroups at 300 clusters), and this cuts the chain from 121 x (distance + sqrt) to 31 x that
+// plus 121 additions (11 -> 4 us at 1080p).  The square root's argument is an integer < 2^24: sqrt_int24 is sqrtf there.
+__global__ __launch_bounds__(256) void sample_clusters_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
+                                                             const kde_float3* __restrict__ pts,
+                                                             kde_superpixel* __restrict__ mean,
+                                                             kde_float3* __restrict__ centers)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane >> 4, tid = lane & 15;
     const int cluster = blockIdx.x * 4 + sub;
     const int nclusters = g.rows * g.cols;
@@ -38,10 +43,11 @@ __global__ __launch_bounds__(64) void sample_clusters_kernel(DaspGeom g, const u
     const uint8_t* ca = bgr + ((size_t)around_y * g.width + around_x) * 3;
     const float a0 = (float)ca[0], a1 = (float)ca[1], a2 = (float)ca[2];
     // The 11x11 taps are addressed ABSOLUTELY in the reference (idx = yy*width + xx, .cu:52-54), i.e. they are the
-    // same 121 colours for every candidate of every cluster: stage them once per wavefront instead of issuing
+    // same 121 colours for every candidate of every cluster: stage them once per workgroup instead of issuing
     // 363 dependent byte loads per thread.
     __shared__ float taps[121][3];
-    for (int i = lane; i < 121; i += 64) {
+    __shared__ float grs[121][64];             // [tap][candidate lane]: consecutive lanes, consecutive words
+    for (int i = threadIdx.x; i < 121; i += 256) {
         const int yy = i / 11 - 5, xx = i % 11 - 5;
         const long idx = (long)yy * g.width + xx;
         float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
@@ -55,11 +61,16 @@ __global__ __launch_bounds__(64) void sample_clusters_kernel(DaspGeom g, const u
         taps[i][2] = t2;
     }
     __syncthreads();
+    for (int i = wv; i < 121; i += 4) {
+        const float d0 = a0 - taps[i][0], d1 = a1 - taps[i][1], d2 = a2 - taps[i][2];
+        grs[i][lane] = sqrt_int24(d0 * d0 + d1 * d1 + d2 * d2);     // integer-valued, <= 3 * 255^2: exact like sqrtf
+    }
+    __syncthreads();
+    if (wv != 0) return;
     float sumG = 0.0f;
     int count = 0;
     for (int i = 0; i < 121; i++) {               // yy outer, xx inner: the reference's summation order
-        const float d0 = a0 - taps[i][0], d1 = a1 - taps[i][1], d2 = a2 - taps[i][2];
-        const float gr = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+        const float gr = grs[i][lane];
         count += gr > 0.0f ? 1 : 0;
         sumG += gr;
     }
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const
 int launch_dasp_sample(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
                        kde_float3* centers, hipStream_t s)
 {
-    hipLaunchKernelGGL(sample_clusters_kernel, dim3(ceil_div(g.rows * g.cols, 4)), dim3(64), 0, s, g, bgr, pts, mean,
+    hipLaunchKernelGGL(sample_clusters_kernel, dim3(ceil_div(g.rows * g.cols, 4)), dim3(256), 0, s, g, bgr, pts, mean,
                        centers);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;

@@ -579,6 +579,8 @@ struct Enh7PkDev {
     int width, height;
     float kc1, sd, t2_skip, exp_zero;
     int kinf;                                   // first rank whose table scale is +inf in the reference's arithmetic
+    int kfree;                                  // from this rank on the table's threshold is 1: a colour factor is either
+                                                // skipped (cd >= 1) or exp(0) = 1 (cd == 0) -- no colour arithmetic needed
     __attribute__((aligned(8))) float lsp[98];  // [(row*7 + unit)*2 + pixel of the pair]: log2 of the spatial table
     float tinv[50];                             // finite
     float tthr[50];
@@ -778,12 +780,25 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
     }
 
     // ---- pass 3: every valid tap, colour sigma mutating with the tap's rank (.cu:158-195) ------------
+    // Rank cut-off: once the decayed table sigma c_k is so small that 2 c_k^2 * x0 < 1 (rank kfree = 6 at the
+    // reference's ColorSigma), a tap's colour factor is exp(-cd / (2 cs^2)) with cs = max(a, c_k): for cd >= 1 it has
+    // underflowed to 0 and is SKIPPED, for cd == 0 it is exp(0) = 1 -- either way the weight is S * df, provided the
+    // adaptive sigma a is not large itself (thr_a <= 1 <=> 2 a^2 * x0 <= 1; a = 5 dev / avg^2 is ~1e-5 on real depth).
+    // So as soon as every lane of the wavefront has passed rank kfree on both of its pixels, the remaining ROWS run a
+    // loop without any colour arithmetic (12 instead of 28 issue slots per unit; typically rows 1..6 of 7).  Lanes
+    // with holes in their first row simply keep the wave in the general loop one row longer.
     const e_f2 T2 = e_bcast(a.t2_skip), kBig = e_bcast(0x1p100f), sd2 = e_bcast(a.sd);
     e_f2 num = e_bcast(0.0f), den = e_bcast(0.0f);
     uint32_t rank0 = 0, rank1 = 0;           // byte offsets into s_t (8 bytes per rank)
     const char* tbase = reinterpret_cast<const char*>(s_t);
+    const float tinv_last = a.tinv[a.kfree > 0 ? a.kfree - 1 : 0];
+    const bool a_small = nthr_a.x >= -1.0f && nthr_a.y >= -1.0f && inv_a.x >= tinv_last && inv_a.y >= tinv_last;
+    const uint32_t free_off = (uint32_t)a.kfree * 8u;
+    int row = 0;
+    // general loop: rows whose taps may still be below rank kfree on some lane of the wavefront
 #pragma unroll 1
-    for (int i = 0; i < WIN; i++) {
+    for (; row < WIN; row++) {
+        const int i = row;
         e_f2 dp[SEGP], vp[SEGP];
         e_u2 cp[SEGP], np[SEGP];
         load_f(s_d, i, dp);
@@ -818,6 +833,32 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
             const e_f2 t = (dq - wavg) * sd2;
             const e_f2 md = e_mul_clamp(e_fma(-t, t, T2), kBig);          // 0 <=> underflowed depth factor skipped
             const e_f2 a2 = e_fma(-(t * md), t, ac);
+            const e_f2 f = e_f2{__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+            num = e_fma(dq, f, num);
+            den = e_fma(pick_f(vp, u), f, den);
+        }
+        // every (active) lane past rank kfree on both pixels, with a small adaptive sigma?  then no later tap needs colour
+        const bool lane_free = a_small && rank0 >= free_off && rank1 >= free_off;
+        if (__builtin_amdgcn_ballot_w64(!lane_free) == 0) {       // wave-uniform
+            row++;
+            break;
+        }
+    }
+    // colour-free loop for the remaining rows
+#pragma unroll 1
+    for (; row < WIN; row++) {
+        const int i = row;
+        e_f2 dp[SEGP], vp[SEGP];
+        load_f(s_d, i, dp);
+#pragma unroll
+        for (int m = 0; m < SEGP; m++) vp[m] = e_add_clamp(dp[m], dp[m]);
+#pragma unroll
+        for (int u = 0; u < WIN; u++) {
+            const e_f2 lsj = *reinterpret_cast<const e_f2*>(&a.lsp[(i * WIN + u) * 2]);
+            const e_f2 dq = pick_f(dp, u);
+            const e_f2 t = (dq - wavg) * sd2;
+            const e_f2 md = e_mul_clamp(e_fma(-t, t, T2), kBig);          // 0 <=> underflowed depth factor skipped
+            const e_f2 a2 = e_fma(-(t * md), t, lsj);
             const e_f2 f = e_f2{__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
             num = e_fma(dq, f, num);
             den = e_fma(pick_f(vp, u), f, den);
@@ -934,6 +975,7 @@ int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bg
         d.tinv[0] = 1.0f;    // rank 0 = only invalid taps so far (their weight is multiplied by 0 anyway)
         d.tthr[0] = 0.0f;
         d.kinf = 50;
+        d.kfree = 50;
         for (int k = 1; k < 50; k++) {
             c *= 0.3f;
             const float den = 2 * (c * c);
@@ -951,6 +993,8 @@ int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bg
                 d.tthr[k] = -(float)lo;
             }
         }
+        // first rank from which every threshold is 1 (the sigmas only shrink with the rank: once 1, always 1)
+        for (int k = 49; k >= 1 && d.tthr[k] >= -1.0f; k--) d.kfree = k;
         hipLaunchKernelGGL(enhance7_pk_kernel, dim3(ceil_div(width, kE7BX * 2), ceil_div(height, kE7BY)),
                            dim3(kE7BX * kE7BY), 0, s, d);
         KDE_HIP_TRY(hipGetLastError());

@@ -26,6 +26,8 @@
 // keeps each XCD on a contiguous band of tiles so halos are shared in that XCD's L2.
 #include "kde_internal.h"
 
+#include <type_traits>
+
 namespace kde {
 namespace {
 
@@ -259,6 +261,8 @@ __device__ __forceinline__ f2 pk_mul_clamp(f2 a, f2 b)
     return r;
 }
 
+// second launch bound = waves per SIMD the register allocator must leave room for: the four rule-specialised bodies
+// below share one kernel, and without it the window-19 instance grew from 131 to 182 VGPRs (3 -> 2 waves per SIMD)
 template <int WIN, int NP, int BX, int BY, bool CACHE, bool CSKIP, bool VL>
 __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
 {
@@ -303,13 +307,42 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     const uint8_t* __restrict__ guide = a.guide + frame * 3;
     const int tid = threadIdx.x;
 
+    // Tile statistics for the rule elision below: range of the valid depths and per-channel range of the colours of
+    // the in-image pixels this workgroup stages (tile + halo = every tap and every centre the workgroup can see).
+    // Positive floats order like their bit patterns, so everything is reduced as uint32.
+    // (Only for windows >= 9: at windows 5 and 7 a thread has 25 / 49 units of work and the statistics cost more than
+    //  the elided instructions return -- measured 33.9 vs 28.8 us on one 1080p frame at window 5.)
+    constexpr bool ELIDE = WIN >= 9;
+    __shared__ uint32_t s_stat[8];           // dmin, dmax, (min, max) of b, g, r
+    if (ELIDE) {
+        if (tid < 8) s_stat[tid] = (tid == 0 || (tid >= 2 && !(tid & 1))) ? 0xffffffffu : 0u;
+        __syncthreads();                     // the initial values are in place before any wavefront's atomics below
+    }
+    uint32_t st_dmin = 0x7f800000u, st_dmax = 0u, st_cmin[3] = {255u, 255u, 255u}, st_cmax[3] = {0u, 0u, 0u};
+    auto stat = [&](float dv, uint32_t c, bool inside) {        // dv: staged depth (0 = invalid)
+        if (!ELIDE) return;
+        if (dv > 0.0f) {
+            st_dmin = min(st_dmin, __float_as_uint(dv));
+            st_dmax = max(st_dmax, __float_as_uint(dv));
+        }
+        if (inside) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const uint32_t v = (c >> (8 * ch)) & 0xffu;
+                st_cmin[ch] = min(st_cmin[ch], v);
+                st_cmax[ch] = max(st_cmax[ch], v);
+            }
+        }
+    };
+
     if (!VL) {
         for (int i = tid; i < P * LH; i += NT) {
             const int ly = i / P, lx = i - ly * P;
             const int gx = o + lx, gy = y0 - R + ly;
             float d = 0.0f;
             uint32_t c = 0;
-            if (gx >= 0 && gx < a.width && gy >= 0 && gy < a.height) {
+            const bool inside = gx >= 0 && gx < a.width && gy >= 0 && gy < a.height;
+            if (inside) {
                 const size_t q = (size_t)gy * a.width + gx;
                 d = depth[q];
                 const uint8_t* p = guide + q * 3;
@@ -319,6 +352,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
             s_d[i] = valid ? d : 0.0f;
             s_c[i] = c;
             s_n[i] = (kMagic + kOff) - dot4(c, c, 0);
+            stat(valid ? d : 0.0f, c, inside);
         }
     }
     for (int g = tid; VL && g < G * LH; g += NT) {
@@ -354,13 +388,46 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
             const bool valid = d[k] > 50.0f;
             d[k] = valid ? d[k] : 0.0f;
             nn[k] = (kMagic + kOff) - dot4(c[k], c[k], 0);
+            stat(d[k], c[k], gy >= 0 && gy < a.height && gx + k >= 0 && gx + k < a.width);
         }
         const int li = ly * P + 4 * gi;
         *reinterpret_cast<float4*>(&s_d[li]) = make_float4(d[0], d[1], d[2], d[3]);
         *reinterpret_cast<uint4*>(&s_c[li]) = make_uint4(c[0], c[1], c[2], c[3]);
         *reinterpret_cast<uint4*>(&s_n[li]) = make_uint4(nn[0], nn[1], nn[2], nn[3]);
     }
+    if (ELIDE) {   // wavefront reduction (xor butterflies), then one LDS atomic per wavefront and statistic
+        uint32_t v[8] = {st_dmin, st_dmax, st_cmin[0], st_cmax[0], st_cmin[1], st_cmax[1], st_cmin[2], st_cmax[2]};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const uint32_t ov = (uint32_t)__shfl_xor((int)v[k], m, 64);
+                v[k] = (k & 1) ? max(v[k], ov) : min(v[k], ov);
+            }
+        }
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k & 1) atomicMax(&s_stat[k], v[k]);
+                else atomicMin(&s_stat[k], v[k]);
+            }
+        }
+    }
     __syncthreads();
+
+    // Rule elision (workgroup-uniform): the reference's "factor that underflowed to 0 is skipped" tests (Q1) cost 2 packed
+    // instructions per unit and pass for the colour rule and 3 per unit for the depth rule.  Neither can trip anywhere
+    // in this tile when the tile's own value ranges stay below the thresholds:
+    //   colour: cd(p, q) <= sum_c (max_c - min_c)^2 over the staged pixels           < cd_skip
+    //   depth:  |d_q - avg_p| <= max - min of the staged valid depths (avg_p is a mean of them), x sd  < t_skip
+    // The full-rule code is kept for the tiles that straddle a colour or depth edge.
+    bool tile_c = CSKIP, tile_d = true;
+    if (ELIDE) {
+        const int rb = (int)s_stat[3] - (int)s_stat[2], rg = (int)s_stat[5] - (int)s_stat[4], rr = (int)s_stat[7] - (int)s_stat[6];
+        if (s_stat[3] >= s_stat[2]) tile_c = CSKIP && (rb * rb + rg * rg + rr * rr >= a.cd_skip);
+        const float range = __uint_as_float(s_stat[1]) - __uint_as_float(s_stat[0]);       // -inf when no valid depth was staged
+        tile_d = !(range * a.sd * 1.0001f < a.t_skip);
+    }
 
     const int tx = tid % BX, ty = tid / BX;
     const int xb = x0 + tx * PX, y = y0 + ty;
@@ -396,7 +463,8 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     const f2 kBig = bcast(0x1p100f);
 
     // argument (log2 domain, without the row factor) of S*cf for the two taps of unit u of pair pp
-    auto unit_arg = [&](const u2* cp, const u2* np, int pp, int i, int u) -> f2 {
+    auto unit_arg = [&](auto cs_tag, const u2* cp, const u2* np, int pp, int i, int u) -> f2 {
+        constexpr bool CS = decltype(cs_tag)::value;
         uint32_t c0, c1, n0, n1;
         if (u <= HALF) {                       // straight
             c0 = cp[pp + u].x; c1 = cp[pp + u].y; n0 = np[pp + u].x; n1 = np[pp + u].y;
@@ -411,7 +479,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         // -cd exactly, then ONE rounding in the fma: a1 = log2(S[i][j]) - kc*cd
         const f2 ncd = f2{__uint_as_float(u0), __uint_as_float(u1)} + negC[pp];
         const f2 lsj = *reinterpret_cast<const f2*>(&a.tab[(i * WIN + u) * 2]);
-        if (CSKIP) return pk_fma(ncd, pk_add_clamp(ncd, Tc) * kc2, lsj);   // Q1: underflowed colour factor skipped
+        if (CS) return pk_fma(ncd, pk_add_clamp(ncd, Tc) * kc2, lsj);   // Q1: underflowed colour factor skipped
         return pk_fma(ncd, kc2, lsj);
     };
     auto unit_depth = [&](const f2* dp, int pp, int u) -> f2 {
@@ -420,7 +488,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         return f2{dp[pp].y, dp[pp + HALF].x};
     };
 
-    auto pass1_row = [&](int i) {
+    auto pass1_row = [&](auto cs_tag, int i) {
         f2 dp[SEGP], vp[SEGP];
         u2 cp[SEGP], np[SEGP];
         const int rb = (ty + i) * P + sx;
@@ -435,7 +503,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         for (int pp = 0; pp < NP; pp++) {
 #pragma unroll
             for (int u = 0; u < WIN; u++) {
-                const f2 a1 = unit_arg(cp, np, pp, i, u);
+                const f2 a1 = unit_arg(cs_tag, cp, np, pp, i, u);
                 if (CACHE) arg[(i * NP + pp) * WIN + u] = a1;
                 const f2 f = f2{__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
                 wsum[pp] = pk_fma(unit_depth(dp, pp, u), f, wsum[pp]);
@@ -443,24 +511,10 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
             }
         }
     };
-    if (CACHE) {
-#pragma unroll
-        for (int i = 0; i < WIN; i++) pass1_row(i);
-    } else {
-#pragma unroll 1
-        for (int i = 0; i < WIN; i++) pass1_row(i);
-    }
-
     f2 c2[NP], num[NP], den[NP];
-#pragma unroll
-    for (int pp = 0; pp < NP; pp++) {
-        // window averages (wgt == 0 handled at the store); v_rcp_f32 is 1 ulp, the same order as the
-        // summation-order noise already present in wsum
-        c2[pp] = wsum[pp] * f2{__builtin_amdgcn_rcpf(wgt[pp].x), __builtin_amdgcn_rcpf(wgt[pp].y)};
-        num[pp] = den[pp] = bcast(0.0f);
-    }
 
-    auto pass2_row = [&](int i) {
+    auto pass2_row = [&](auto cs_tag, auto ds_tag, int i) {
+        constexpr bool DS = decltype(ds_tag)::value;
         f2 dp[SEGP], vp[SEGP];
         u2 cp[SEGP], np[SEGP];
         const int rb = (ty + i) * P + sx;
@@ -477,23 +531,64 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         for (int pp = 0; pp < NP; pp++) {
 #pragma unroll
             for (int u = 0; u < WIN; u++) {
-                const f2 a1 = CACHE ? arg[(i * NP + pp) * WIN + u] : unit_arg(cp, np, pp, i, u);
+                const f2 a1 = CACHE ? arg[(i * NP + pp) * WIN + u] : unit_arg(cs_tag, cp, np, pp, i, u);
                 const f2 dq = unit_depth(dp, pp, u);
                 const f2 t = (dq - c2[pp]) * bcast(a.sd);    // subtract first: see the scalar kernel
-                const f2 m = pk_mul_clamp(pk_fma(-t, t, T2), kBig);        // Q1: underflowed depth factor skipped
-                const f2 a2 = pk_fma(-(t * m), t, a1);
+                f2 a2;
+                if (DS) {
+                    const f2 m = pk_mul_clamp(pk_fma(-t, t, T2), kBig);    // Q1: underflowed depth factor skipped
+                    a2 = pk_fma(-(t * m), t, a1);
+                } else {
+                    a2 = pk_fma(-t, t, a1);                                  // the tile's depth range cannot reach the threshold
+                }
                 const f2 f = f2{__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
                 num[pp] = pk_fma(dq, f, num[pp]);
                 den[pp] = pk_fma(unit_depth(vp, pp, u), f, den[pp]);
             }
         }
     };
-    if (CACHE) {
+    // both passes, specialised on which Q1 rules this tile needs
+    auto run = [&](auto cs_tag, auto ds_tag) {
+        if (CACHE) {
 #pragma unroll
-        for (int i = 0; i < WIN; i++) pass2_row(i);
-    } else {
+            for (int i = 0; i < WIN; i++) pass1_row(cs_tag, i);
+        } else {
 #pragma unroll 1
-        for (int i = 0; i < WIN; i++) pass2_row(i);
+            for (int i = 0; i < WIN; i++) pass1_row(cs_tag, i);
+        }
+#pragma unroll
+        for (int pp = 0; pp < NP; pp++) {
+            // window averages (wgt == 0 handled at the store); v_rcp_f32 is 1 ulp, the same order as the
+            // summation-order noise already present in wsum
+            c2[pp] = wsum[pp] * f2{__builtin_amdgcn_rcpf(wgt[pp].x), __builtin_amdgcn_rcpf(wgt[pp].y)};
+            num[pp] = den[pp] = bcast(0.0f);
+        }
+        if (CACHE) {
+#pragma unroll
+            for (int i = 0; i < WIN; i++) pass2_row(cs_tag, ds_tag, i);
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < WIN; i++) pass2_row(cs_tag, ds_tag, i);
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    // Four bodies for the small windows.  For the wide ones only {both rules, no rule}: a body with exactly one rule made
+    // the window-19 instance 182-188 VGPRs instead of 131 (2 instead of 3 waves per SIMD), which costs more than the
+    // partial elision gains.
+    if constexpr (!ELIDE) {
+        run(std::integral_constant<bool, CSKIP>{}, T_{});
+    } else if constexpr (WIN >= 15) {
+        if ((CSKIP && tile_c) || tile_d) run(std::integral_constant<bool, CSKIP>{}, T_{});
+        else run(F_{}, F_{});
+    } else {
+        if (!CSKIP || !tile_c) {
+            if (tile_d) run(F_{}, T_{});
+            else run(F_{}, F_{});
+        } else {
+            if (tile_d) run(T_{}, T_{});
+            else run(T_{}, F_{});
+        }
     }
 
     float* __restrict__ op = a.out + frame + (size_t)y * a.width + xb;
@@ -559,10 +654,12 @@ const Variant kVariants[] = {
     K(5, 1, 32, 8, true),   K(5, 1, 16, 16, true),  KS(5, 1, 16, 16, true),  K(5, 2, 32, 8, true),  K(5, 1, 32, 8, false),
     V(5, 2, 32, 8, true),   V(5, 1, 64, 4, true),
     K(7, 1, 16, 16, true),  K(7, 1, 32, 8, true),   KS(7, 1, 32, 8, true),  K(7, 1, 32, 8, false),  V(7, 1, 64, 4, true),
+    // tiles (pixels) of BASELINE config 3's sweep: 64x16 / 32x16 / 64x8 / 128x8 with 4 or 2 pixels per thread (packed pairs),
+    // and the scalar kernels at 2 and 1 pixels per thread (32x16, 32x8)
     KS(11, 2, 16, 16, false), K(11, 2, 16, 16, false), KS(11, 1, 16, 16, false), K(11, 1, 16, 16, false), K(11, 1, 32, 8, false),
-    V(11, 2, 16, 16, false),
+    KS(11, 1, 32, 8, false), KS(11, 2, 32, 8, false), V(11, 2, 16, 16, false), V(11, 1, 32, 8, false),
     KS(19, 2, 16, 16, false), K(19, 2, 16, 16, false), KS(19, 1, 16, 16, false), K(19, 1, 16, 16, false), K(19, 1, 32, 8, false),
-    V(19, 2, 16, 16, false),
+    KS(19, 1, 32, 8, false), KS(19, 2, 32, 8, false), V(19, 2, 16, 16, false), V(19, 1, 32, 8, false),
 };
 #undef V
 #undef K
