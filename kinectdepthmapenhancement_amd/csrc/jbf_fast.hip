@@ -650,15 +650,15 @@ struct Variant {
     {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v1", WIN, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, false>}
 const Variant kVariants[] = {
     // the FIRST variant listed for a window is the built-in choice (interleaved A/B sweep on MI355X,
-    // profiles/r01_sweep_k1_variants.log); the others stay selectable for the tile sweep of BASELINE config 3
-    K(5, 1, 32, 8, true),   K(5, 1, 16, 16, true),  KS(5, 1, 16, 16, true),  K(5, 2, 32, 8, true),  K(5, 1, 32, 8, false),
+    // profiles/r02_sweep_k1_variants.log); the others stay selectable for the tile sweep of BASELINE config 3
+    K(5, 1, 16, 16, true),  K(5, 1, 32, 8, true),   KS(5, 1, 16, 16, true),  K(5, 2, 32, 8, true),  K(5, 1, 32, 8, false),
     V(5, 2, 32, 8, true),   V(5, 1, 64, 4, true),
     K(7, 1, 16, 16, true),  K(7, 1, 32, 8, true),   KS(7, 1, 32, 8, true),  K(7, 1, 32, 8, false),  V(7, 1, 64, 4, true),
     // tiles (pixels) of BASELINE config 3's sweep: 64x16 / 32x16 / 64x8 / 128x8 with 4 or 2 pixels per thread (packed pairs),
     // and the scalar kernels at 2 and 1 pixels per thread (32x16, 32x8)
     KS(11, 2, 16, 16, false), K(11, 2, 16, 16, false), KS(11, 1, 16, 16, false), K(11, 1, 16, 16, false), K(11, 1, 32, 8, false),
     KS(11, 1, 32, 8, false), KS(11, 2, 32, 8, false), V(11, 2, 16, 16, false), V(11, 1, 32, 8, false),
-    KS(19, 2, 16, 16, false), K(19, 2, 16, 16, false), KS(19, 1, 16, 16, false), K(19, 1, 16, 16, false), K(19, 1, 32, 8, false),
+    KS(19, 1, 16, 16, false), KS(19, 2, 16, 16, false), K(19, 2, 16, 16, false), K(19, 1, 16, 16, false), K(19, 1, 32, 8, false),
     KS(19, 1, 32, 8, false), KS(19, 2, 32, 8, false), V(19, 2, 16, 16, false), V(19, 1, 32, 8, false),
 };
 #undef V
