@@ -1,5 +1,7 @@
 """The N>1 path on CPU: world_size-2 gloo process group, contiguous frame blocks, one parameter
-broadcast, no data-path collective."""
+broadcast, no data-path collective.  This file covers the partition / broadcast / reduce LOGIC without a
+GPU (the per-rank filter is a stand-in); tests/test_gpu_sharding.py runs the same two-rank layout with every rank really
+filtering its block through the HIP library and requires a result bit-identical to one process."""
 import os
 import socket
 
