@@ -40,6 +40,15 @@ def test_library_exports_every_declared_symbol(native):
     assert not missing, f"declared in kde_hip.h but not exported: {missing}"
 
 
+def test_hooks_are_not_part_of_the_product_abi(native):
+    """test / measurement hooks live in tools/hooks/libkde_hooks.so (include/kde_test_hooks.h), not in libkde_hip.so"""
+    out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert not {n for n in exported if n.startswith(("kde_test_", "kde_bench_"))}
+    # and everything the library exports with a kde_ prefix is declared in the public header
+    assert {n for n in exported if n.startswith("kde_")} == set(declared_functions())
+
+
 def test_python_binding_covers_the_header(native):
     names = set(declared_functions())
     assert names == set(native.SIGNATURES), (names ^ set(native.SIGNATURES))
