@@ -167,9 +167,25 @@ typedef struct {
 static const double kXZ = 103.97207708399179;      /* 150 ln 2: expf(-x) == 0 (round to nearest) for x beyond */
 static const double kUnder = 0x1p-150;              /* a float32 product at or below this rounds to 0 */
 
-/* both passes in binary64; returns the result (0 = "output is 0"), *band |= 1 when a tap sits in a decision band */
+static const double kUnit = 0x1p-149;               /* the float32 denormal grid */
+
+/* quantisation allowance: the float32 code holds a weight below 2^-126 on the 2^-149 grid (expf rounds to it, and so
+ * does every product), so two faithful float32 evaluations with different expf implementations differ by a grid unit or
+ * two per weight.  q = +-1 moves every weight by 2 units in the direction that raises / lowers the weighted mean around
+ * `centre` (never below 0): the first-order bound of that noise.  q = 0: no change. */
+static inline double quantised(double f, double d, double centre, int q)
+{
+    if (q == 0 || !(f < 0x1p-120)) return f;
+    const double g = f + (double)q * (d >= centre ? 2.0 : -2.0) * kUnit;
+    return g > 0.0 ? g : 0.0;
+}
+
+/* both passes in binary64; returns the result (0 = "output is 0"), *band |= 1 when a tap sits in a decision band.
+ * q1 / q2: quantisation allowance of the first / second pass weights around centre1 / centre2; den_out: the two sums
+ * of weights (to tell whether the allowance can matter at all). */
 static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double avg_rel, double thr_scale,
-                         double und_scale, int* band, double* n_eff)
+                         double und_scale, int* band, double* n_eff, int q1, double centre1, int q2, double centre2,
+                         double* den_out)
 {
     const double U = kUnder * und_scale;
     double wa = 0.0, wt = 0.0, wt2 = 0.0;
@@ -177,10 +193,12 @@ static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double av
         double f = t->base[k];
         if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
         if (f <= U) f = 0.0;
+        else f = quantised(f, t->d[k], centre1, q1);
         wa += t->d[k] * f;
         wt += f;
         wt2 += f * f;
     }
+    if (den_out) den_out[0] = wt, den_out[1] = 0.0;
     if (!(wt > 0.0)) return 0.0;
     if (n_eff) *n_eff = wt * wt / wt2;
     wa = wa / wt * (1.0 + avg_rel);
@@ -195,9 +213,11 @@ static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double av
             if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
             if (f <= U) continue;
         }
+        f = quantised(f, t->d[k], centre2, q2);
         nu += t->d[k] * f;
         de += f;
     }
+    if (den_out) den_out[1] = de;
     return de > 0.0 ? nu / de : 0.0;
 }
 
@@ -305,14 +325,14 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                         }
                     }
                 int band = 0;
-                double n_eff = 1.0;
-                const double r0 = jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &band, &n_eff);
+                double n_eff = 1.0, dens[2] = {0.0, 0.0};
+                const double r0 = jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens);
                 /* rounding of a float32 sum grows with the number of taps that carry weight: the participation
                  * ratio (sum w)^2 / sum w^2; measured 25 ulps at 128 equal weights -> 2.5 sqrt(n_eff) */
                 const double eps_avg = (4.0 + 2.5 * sqrt(n_eff)) * 1.1920928955078125e-7;
                 env_add(&e, r0);
-                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, eps_avg, 1.0, 1.0, &band, NULL));
-                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, -eps_avg, 1.0, 1.0, &band, NULL));
+                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL));
+                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, -eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL));
                 if (band) {
                     flag |= 2;
                     for (int a = -1; a <= 1; a++)
@@ -320,8 +340,20 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                             for (int c = -1; c <= 1; c++) {
                                 int dummy = 0;
                                 env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, a * eps_avg, 1.0 + b * 1.5e-4,
-                                                       1.0 + c * 5e-4, &dummy, NULL));
+                                                       1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL));
                             }
+                }
+                /* a sum of weights so small that the 2^-149 grid is within 1e-6 of it: the float32 value is
+                 * quantisation noise of its own arithmetic -- bracket that noise as well (see quantised()) */
+                const int qa = dens[0] > 0.0 && dens[0] < 0x1p-110, qb = dens[1] > 0.0 && dens[1] < 0x1p-110;
+                if (qa || qb) {
+                    const double wa0 = r0;     /* centre for the first pass: any value inside the depth range splits the taps */
+                    for (int a = (qa ? -1 : 0); a <= (qa ? 1 : 0); a++)
+                        for (int b = (qb ? -1 : 0); b <= (qb ? 1 : 0); b++) {
+                            if (a == 0 && b == 0) continue;
+                            int dummy = 0;
+                            env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &dummy, NULL, a, wa0, b, r0, NULL));
+                        }
                 }
                 env_add(&e, (double)out);
                 if (e.nonzero) {
@@ -881,7 +913,8 @@ typedef struct {
 /* the three passes in binary64 with the float32 code's decisions; a = adaptive sigma as the float32 code formed it.
  * Returns the result (0 = "output is 0", NaN = the Q6 quirk); *band |= 1 when a tap sits in a decision band. */
 static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, int depth_on, float a, double avg_rel,
-                         double thr_scale, double und_scale, int* band, double* n_eff)
+                         double thr_scale, double und_scale, int* band, double* n_eff, int q1, double centre1, int q2,
+                         double centre2, double* den_out)
 {
     const double U = kUnder * und_scale;
     double wa = 0.0, wt = 0.0, wt2 = 0.0;
@@ -892,10 +925,12 @@ static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, i
             f *= exp(-(double)t->cd[k] / (2.0 * (double)color_sigma_in * (double)color_sigma_in));
         if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
         if (f <= U) f = 0.0;
+        else f = quantised(f, t->d[k], centre1, q1);
         wa += t->d[k] * f;
         wt += f;
         wt2 += f * f;
     }
+    if (den_out) den_out[0] = wt, den_out[1] = 0.0;
     if (!(wt > 0.0)) return 0.0;
     if (n_eff) *n_eff = wt * wt / wt2;
     wa = wa / wt * (1.0 + avg_rel);
@@ -917,9 +952,11 @@ static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, i
         }
         if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
         if (f <= U) continue;            /* NaN fails the test and is summed in, as in float32 */
+        if (f == f) f = quantised(f, t->d[k], centre2, q2);
         nu += t->d[k] * f;
         de += f;
     }
+    if (den_out) den_out[1] = de;
     if (de != de || nu != nu) return NAN;
     return de > 0.0 ? nu / de : 0.0;
 }
@@ -1046,12 +1083,12 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                     flag |= 2;
                 }
                 int band = 0;
-                double n_eff = 1.0;
-                const double r0 = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band, &n_eff);
+                double n_eff = 1.0, dens[2] = {0.0, 0.0};
+                const double r0 = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens);
                 const double eps_avg = (4.0 + 2.5 * sqrt(n_eff)) * 1.1920928955078125e-7;
                 for (int v = 0; v < nalt; v++)
                     for (int a = -1; a <= 1; a++) {
-                        const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg, 1.0, 1.0, &band, NULL);
+                        const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL);
                         if (r != r) nan_ok = 1;
                         else env_add(&e, r);
                     }
@@ -1063,10 +1100,22 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                                 for (int c = -1; c <= 1; c++) {
                                     int dummy = 0;
                                     const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg,
-                                                                1.0 + b * 1.5e-4, 1.0 + c * 5e-4, &dummy, NULL);
+                                                                1.0 + b * 1.5e-4, 1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL);
                                     if (r != r) nan_ok = 1;
                                     else env_add(&e, r);
                                 }
+                }
+                /* sums of weights on the float32 denormal grid: bracket the quantisation noise too (see quantised()) */
+                const int qa = dens[0] > 0.0 && dens[0] < 0x1p-110, qb = dens[1] > 0.0 && dens[1] < 0x1p-110;
+                if ((qa || qb) && r0 == r0) {
+                    for (int a = (qa ? -1 : 0); a <= (qa ? 1 : 0); a++)
+                        for (int b = (qb ? -1 : 0); b <= (qb ? 1 : 0); b++) {
+                            if (a == 0 && b == 0) continue;
+                            int dummy = 0;
+                            const double r = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &dummy, NULL, a, r0, b, r0, NULL);
+                            if (r != r) nan_ok = 1;
+                            else env_add(&e, r);
+                        }
                 }
                 if (result != result) nan_ok = 1;
                 else env_add(&e, (double)result);

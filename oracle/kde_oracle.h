@@ -51,7 +51,10 @@ void okde_cv_bilateral_8uc3(const uint8_t* src, int width, int height, size_t sr
  * ill-conditioned in their own first-pass average, so for every pixel the oracle also says what ANY faithful
  * evaluation may return: [lo, hi] spans the binary64 values of the same formula with the first-pass average moved by
  * the rounding a float32 sum cannot avoid and -- where a tap sits within 1.5e-4 of such a decision -- with the
- * decision taken either way; the float32 restatement's own value is included.  flags:
+ * decision taken either way; where a sum of weights lies on the float32 denormal grid (< 2^-110) also with every
+ * weight moved by two grid units (2^-149) in the direction that raises / lowers the result -- the quantisation noise of
+ * the reference's own float32 arithmetic, which two faithful evaluations with different expf implementations do not
+ * share; the float32 restatement's own value is included.  flags:
  *   bit 1 (2)  a tap sits on a Q1 decision (depth-factor underflow at x = 150 ln 2, or a whole weight at the
  *              float32 underflow-to-zero point 2^-150): both outcomes are in [lo, hi]
  *   bit 2 (4)  [lo, hi] is wider than 2e-5 relative (rounding of the average amplified, or the float32 value itself
