@@ -635,8 +635,13 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
     __shared__ __attribute__((aligned(16))) float s_l[LH * P];
     __shared__ __attribute__((aligned(8))) float2 s_t[50];
 
+    __shared__ uint32_t s_rng[2];                 // bit patterns of the smallest / largest valid depth staged (tile + halo)
+
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int tid = threadIdx.x;
+    if (tid < 2) s_rng[tid] = tid == 0 ? 0x7f800000u : 0u;
+    __syncthreads();
+    uint32_t st_min = 0x7f800000u, st_max = 0u;
     for (int i = tid; i < P * LH; i += NT) {
         const int ly = i / P, lx = i - ly * P;
         const int gx = x0 + lx - R, gy = y0 + ly - R;
@@ -654,9 +659,38 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
         s_c[i] = c | (valid ? 0x08000000u : 0u);
         s_n[i] = (kMagic + kOff) - dot4u(c, c);
         s_l[i] = valid ? (float)l : 1.0e9f;          // never within 1 of a label (|label| < 2^24, -1 = unassigned included)
+        if (valid) {                                  // positive floats order like their bit patterns
+            st_min = min(st_min, __float_as_uint(d));
+            st_max = max(st_max, __float_as_uint(d));
+        }
     }
     if (tid < 50) s_t[tid] = make_float2(a.tinv[tid], a.tthr[tid]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        st_min = min(st_min, (uint32_t)__shfl_xor((int)st_min, m, 64));
+        st_max = max(st_max, (uint32_t)__shfl_xor((int)st_max, m, 64));
+    }
+    if ((tid & 63) == 0) {
+        atomicMin(&s_rng[0], st_min);
+        atomicMax(&s_rng[1], st_max);
+    }
     __syncthreads();
+
+    // Is the adaptive sigma a = 5 dev / avg^2 provably small for EVERY pixel of this tile?  dev is a mean of |d - avg|
+    // over taps whose depths (and whose average) lie inside the tile's valid range [dmin, dmax], so a <= 5 (dmax - dmin) /
+    // dmin^2.  "Small" means what pass 3 needs to ignore it: its skip threshold is 1 (fl(1 / 2a^2) >= x0) and its scale
+    // is not below the table's at rank kfree - 1.  Then the per-pixel deviation pass, the division and the threshold
+    // search are skipped; the deviation is only computed for pixels that could hit the 0/0 quirk (below).
+    bool tile_small_a = false;
+    {
+        const float dmin = __uint_as_float(s_rng[0]), dmax = __uint_as_float(s_rng[1]);
+        if (s_rng[1] >= s_rng[0]) {
+            const float ab = 5.0f * (dmax - dmin) / (dmin * dmin) * 1.001f;
+            const float denb = 2.0f * (ab * ab);
+            const float tl = a.tinv[a.kfree > 0 ? a.kfree - 1 : 0];
+            tile_small_a = a.kfree < 50 && (denb == 0.0f || (1.0f / denb >= a.exp_zero * 1.001f && 1.4426950408889634f / denb >= tl * 1.001f));
+        }
+    }
 
     const int tx = tid % kE7BX, ty = tid / kE7BX;
     const int xb = x0 + 2 * tx, y = y0 + ty;
@@ -734,50 +768,53 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
         }
     }
 
-    // ---- pass 2: mean absolute deviation over the same taps (.cu:143-156) ---------------------------
+    // ---- pass 2: mean absolute deviation over the same taps (.cu:143-156) and, from it, the adaptive sigma's scale,
+    // integer skip threshold and "is exactly 0" flag (.cu:171).  Runs before pass 3 when the tile could not prove the
+    // adaptive sigma small, otherwise only afterwards and only for wavefronts with a candidate for the 0/0 quirk.
     const e_f2 wavg = e_f2{wsum.x / wgt.x, wsum.y / wgt.y};    // IEEE: the integer skip thresholds below depend on it
-    e_f2 dev = e_bcast(0.0f), cnt = e_bcast(0.0f);
+    e_f2 inv_a = e_bcast(3.0e38f), nthr_a = e_bcast(-1.0f);     // values of a provably small adaptive sigma
+    bool flat[2] = {false, false};
+    auto adaptive_sigma = [&]() {
+        e_f2 dev = e_bcast(0.0f), cnt = e_bcast(0.0f);
 #pragma unroll 1
-    for (int i = 0; i < WIN; i++) {
-        e_f2 dp[SEGP], lp[SEGP];
-        load_f(s_d, i, dp);
-        load_f(s_l, i, lp);
+        for (int i = 0; i < WIN; i++) {
+            e_f2 dp[SEGP], lp[SEGP];
+            load_f(s_d, i, dp);
+            load_f(s_l, i, lp);
 #pragma unroll
-        for (int u = 0; u < WIN; u++) {
-            const e_f2 m = label_mask(lp, u);
-            const e_f2 e = pick_f(dp, u) - wavg;
-            dev.x = __builtin_fmaf(__builtin_fabsf(e.x), m.x, dev.x);
-            dev.y = __builtin_fmaf(__builtin_fabsf(e.y), m.y, dev.y);
-            cnt = cnt + m;
+            for (int u = 0; u < WIN; u++) {
+                const e_f2 m = label_mask(lp, u);
+                const e_f2 e = pick_f(dp, u) - wavg;
+                dev.x = __builtin_fmaf(__builtin_fabsf(e.x), m.x, dev.x);
+                dev.y = __builtin_fmaf(__builtin_fabsf(e.y), m.y, dev.y);
+                cnt = cnt + m;
+            }
         }
-    }
-
-    // ---- per pixel: adaptive sigma -> scale and integer skip threshold (.cu:171) ----------------------
-    e_f2 inv_a, nthr_a;
-    bool flat[2];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        float deviation = dev[h];
-        if (cnt[h] != 0.0f) deviation /= cnt[h];
-        // 5.0 is a double literal, pow(float,float) is float
-        const float asig = (float)(5.0 * (double)deviation / (double)(wavg[h] * wavg[h]));
-        const float den_a = 2 * (asig * asig);
-        flat[h] = den_a == 0.0f;
-        inv_a[h] = flat[h] ? 3.0e38f : fminf(1.4426950408889634f / den_a, 3.0e38f);
-        float thr_a;                         // smallest integer cd with fl(cd / den_a) >= x0 (exact)
-        if (flat[h]) {
-            thr_a = 1.0f;                    // cd/0 = inf for cd >= 1; 0/0 = NaN is not ">= x0" (post-pass below)
-        } else if (den_a != den_a) {
-            thr_a = 400000.0f;               // NaN sigma (non-finite depths): nothing compares ">= x0"
-        } else {
-            float c0 = ceilf(a.exp_zero * den_a);
-            c0 = fminf(fmaxf(c0, 0.0f), 400000.0f);
-            while (c0 > 0.0f && (c0 - 1.0f) / den_a >= a.exp_zero) c0 -= 1.0f;
-            while (c0 < 400000.0f && !(c0 / den_a >= a.exp_zero)) c0 += 1.0f;
-            thr_a = c0;
+        for (int h = 0; h < 2; h++) {
+            float deviation = dev[h];
+            if (cnt[h] != 0.0f) deviation /= cnt[h];
+            // 5.0 is a double literal, pow(float,float) is float
+            const float asig = (float)(5.0 * (double)deviation / (double)(wavg[h] * wavg[h]));
+            const float den_a = 2 * (asig * asig);
+            flat[h] = den_a == 0.0f;
+            inv_a[h] = flat[h] ? 3.0e38f : fminf(1.4426950408889634f / den_a, 3.0e38f);
+            float thr_a;                         // smallest integer cd with fl(cd / den_a) >= x0 (exact)
+            if (flat[h]) {
+                thr_a = 1.0f;                    // cd/0 = inf for cd >= 1; 0/0 = NaN is not ">= x0" (post-pass below)
+            } else if (den_a != den_a) {
+                thr_a = 400000.0f;               // NaN sigma (non-finite depths): nothing compares ">= x0"
+            } else {
+                float c0 = ceilf(a.exp_zero * den_a);
+                c0 = fminf(fmaxf(c0, 0.0f), 400000.0f);
+                while (c0 > 0.0f && (c0 - 1.0f) / den_a >= a.exp_zero) c0 -= 1.0f;
+                while (c0 < 400000.0f && !(c0 / den_a >= a.exp_zero)) c0 += 1.0f;
+                thr_a = c0;
+            }
+            nthr_a[h] = -thr_a;
         }
-        nthr_a[h] = -thr_a;
-    }
+    };
+    if (!tile_small_a) adaptive_sigma();
 
     // ---- pass 3: every valid tap, colour sigma mutating with the tap's rank (.cu:158-195) ------------
     // Rank cut-off: once the decayed table sigma c_k is so small that 2 c_k^2 * x0 < 1 (rank kfree = 6 at the
@@ -870,6 +907,26 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
     for (int h = 0; h < 2; h++) {
         res[h] = 0.0f;
         if (wgt[h] > 0.0f) res[h] = (den[h] == 0.0f) ? 0.0f : num[h] / den[h];
+    }
+    // In a tile with a provably small adaptive sigma the deviation has not been computed yet.  It only matters for the
+    // 0/0 quirk below, which needs a valid tap of the centre's exact colour at a rank >= kinf (47): such a tap can only
+    // be one of the last 50 - kinf taps of the window (rank <= position + 1).  Wavefronts without such a pixel are done.
+    if (tile_small_a) {
+        bool cand = false;
+        if (a.kinf <= WIN * WIN) {
+            // ... and the quirk needs a deviation of exactly 0, i.e. EVERY valid tap of the centre's label equal to the
+            // average -- the centre itself is such a tap when it is valid, so a valid centre that differs rules it out
+            const int lc = (ty + R) * P + sx + R;
+            const float dc0 = s_d[lc], dc1 = s_d[lc + 1];
+            const bool may0 = wgt.x > 0.0f && (dc0 == 0.0f || dc0 == wavg.x), may1 = wgt.y > 0.0f && (dc1 == 0.0f || dc1 == wavg.y);
+#pragma unroll 1
+            for (int pos = a.kinf - 1 < 0 ? 0 : a.kinf - 1; pos < WIN * WIN; pos++) {
+                const int li = (ty + pos / WIN) * P + sx + pos % WIN;
+                cand |= may0 && s_d[li] > 0.0f && (s_c[li] & 0x00ffffffu) == cc[0];
+                cand |= may1 && s_d[li + 1] > 0.0f && (s_c[li + 1] & 0x00ffffffu) == cc[1];
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(cand) != 0) adaptive_sigma();       // wave-uniform; sets flat[]
     }
     // Q6 post-pass (rare): flat patch and a valid tap of the centre's exact colour whose rank has a zero table
     // denominator -> the reference evaluates 0/0 = NaN and the NaN reaches the result
