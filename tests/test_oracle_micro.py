@@ -450,3 +450,90 @@ def test_envelope_of_k10_admits_nan_only_next_to_the_flat_patch_quirk(oracle):
     assert not np.isnan(ref2).any() and ((env2.flags & oracle.Env.NAN_OK) != 0).sum() == 0
     nz = ref2 != 0
     assert np.all(ref2[nz] >= env2.lo[nz] * (1 - 1e-12)) and np.all(ref2[nz] <= env2.hi[nz] * (1 + 1e-12))
+
+
+# ---- K10: a literal scalar port of depthmap_enhancement written from the CUDA text, independent of kde_oracle.c ----
+def _enhance_port(rd, bgr, labels, spatial, window=7, color_sigma_in=50.0, depth_sigma=70.0):
+    """EdgeRefinedSuperpixel.cu:104-205 in numpy float32 scalars, reading the phase-start depth (D3).  np.exp on a
+    float32 is not libm's expf to the last ulp, so the comparison below allows 2e-6."""
+    H, W = rd.shape
+    hw = window // 2
+    out = np.zeros((H, W), F)
+    c = bgr.astype(np.float32)
+    with np.errstate(all="ignore"):
+        for y in range(H):
+            for x in range(W):
+                cs = F(color_sigma_in)
+                wavg, weight = F(0), F(0)
+                for i in range(-hw, hw + 1):
+                    for j in range(-hw, hw + 1):
+                        xj, yi = x + j, y + i
+                        if 0 <= xj < W and 0 <= yi < H and rd[yi, xj] > F(50) and labels[y, x] == labels[yi, xj]:
+                            d0, d1, d2 = c[y, x] - c[yi, xj]
+                            cd = F(F(d0 * d0) + F(d1 * d1)) + F(d2 * d2)
+                            cf = np.exp(F(-cd / F(F(2) * F(cs * cs)))) if cs != 0 else F(0)
+                            f = F(1)
+                            s = spatial[i + hw, j + hw]
+                            if s != 0:
+                                f = F(f * s)
+                            if cf != 0:
+                                f = F(f * cf)
+                            wavg = F(wavg + F(rd[yi, xj] * f))
+                            weight = F(weight + f)
+                if not weight > 0:
+                    continue
+                wavg = F(wavg / weight)
+                count, dev = 0, F(0)
+                for i in range(-hw, hw + 1):
+                    for j in range(-hw, hw + 1):
+                        xj, yi = x + j, y + i
+                        if 0 <= xj < W and 0 <= yi < H and rd[yi, xj] > F(50) and labels[y, x] == labels[yi, xj]:
+                            dev = F(dev + abs(F(rd[yi, xj] - wavg)))
+                            count += 1
+                if count:
+                    dev = F(dev / F(count))
+                num, den = F(0), F(0)
+                for i in range(-hw, hw + 1):
+                    for j in range(-hw, hw + 1):
+                        xj, yi = x + j, y + i
+                        if 0 <= xj < W and 0 <= yi < H and rd[yi, xj] > F(50):
+                            d0, d1, d2 = c[y, x] - c[yi, xj]
+                            cd = F(F(d0 * d0) + F(d1 * d1)) + F(d2 * d2)
+                            cf = F(0)
+                            if cs != 0:
+                                a = F(5.0 * float(dev) / float(F(wavg * wavg)))          # double arithmetic, then float
+                                cs = a if a > F(cs * F(0.3)) else F(cs * F(0.3))
+                                cf = np.exp(F(-cd / F(F(2) * F(cs * cs))))
+                            dd = F(rd[yi, xj] - wavg)
+                            df = np.exp(F(-F(dd * dd) / F(F(2) * F(F(depth_sigma) * F(depth_sigma))))) if depth_sigma != 0 else F(0)
+                            f = F(1)
+                            s = spatial[i + hw, j + hw]
+                            if s != 0:
+                                f = F(f * s)
+                            if cf != 0:                     # NaN != 0 is True: the 0/0 quirk multiplies the NaN in
+                                f = F(f * cf)
+                            if df != 0:
+                                f = F(f * df)
+                            num = F(num + F(rd[yi, xj] * f))
+                            den = F(den + f)
+                out[y, x] = F(0) if den == 0 else F(num / den)
+    return out
+
+
+def test_enhance_matches_independent_python_port(oracle):
+    rng = np.random.default_rng(11)
+    H, W = 13, 17
+    labels = ((np.arange(W)[None, :] // 6) + 3 * (np.arange(H)[:, None] // 5)).astype(np.int32)
+    depth = (900 + 250 * labels + rng.normal(0, 6, (H, W))).astype(F)
+    depth[rng.random((H, W)) < 0.08] = 0                      # holes: ranks differ from tap positions
+    depth[2:6, 2:9] = 1536.0                                  # an exactly flat stretch inside one label
+    bgr = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    bgr[:, 8:12] = (40, 80, 120)                              # equal colours: cd == 0 taps
+    labels[6, 6] = 77                                         # an isolated label (single same-label tap)
+    spatial = oracle.spatial_table(7, 30.0)
+    want = _enhance_port(depth, bgr, labels, spatial)
+    got = oracle.ers_enhance(depth, bgr, labels)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got == 0, want == 0)
+    fin = np.isfinite(want) & (want != 0)
+    assert fin.sum() > 150
+    assert np.max(np.abs(got[fin] - want[fin]) / np.abs(want[fin])) < 2e-6
