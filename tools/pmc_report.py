@@ -74,6 +74,10 @@ def main():
                              "vgprs": int(row.get("VGPR_Count", 0) or 0), "sgprs": int(row.get("SGPR_Count", 0) or 0)}
 
     out = {"source": "rocprofv3 --pmc, one counter group per pass (tools/profile_round.sh); MI355X",
+           "note": "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE: the factor 2 (128-byte requests tallied at 64 bytes on gfx950) is "
+                   "calibrated in this run on a float4 copy (fetch_correction_measured); for kernels with narrower loads it is "
+                   "not separately calibrated -- K1's dword / byte tile loads reproduce their algorithmic 7 B/pixel with it. "
+                   "Single-frame working sets are cache-resident: their figures count fabric requests, not DRAM traffic.",
            "command": a.command, "kernel_source_sha16": source_hash(), "kernels": []}
     corr = None
     for (name, grid), e in sorted(table.items()):
