@@ -81,10 +81,14 @@ __device__ __forceinline__ void edge_rule(int pos, int len, int half, FL L, FC C
 // `pos`, and how far its outward search must reach to do so, is static per source:
 //   left branch  (tp = s-d): pos in [tp+1, s]   <=> s >= pos   and d >= s-pos+1
 //   right branch (tp = s+d): pos in [s+1, tp-1] <=> s <  pos   and d >= pos-s+1, cascade over D(s..pos)
-template <int HALF, typename FL, typename FC, typename FD>
+// INTERIOR: the caller guarantees [pos - 2 - HALF, pos + 3 + HALF] lies inside the line, so no bound is tested.
+template <int HALF, bool INTERIOR, typename FL, typename FC, typename FD>
 __device__ __forceinline__ void edge_rule_window(int pos, int len, FL L, FC C, FD D, int32_t& out_label, float& out_depth)
 {
-    auto clampk = [&](int k) { return k < 0 ? 0 : (k >= len ? len - 1 : k); };   // out-of-line values are never used
+    auto clampk = [&](int k) {   // out-of-line values are never used
+        if constexpr (INTERIOR) return k;
+        else return k < 0 ? 0 : (k >= len ? len - 1 : k);
+    };
     int32_t Lw[6], Cw[5 + 2 * HALF];
     float Dw[4];
 #pragma unroll
@@ -93,7 +97,7 @@ __device__ __forceinline__ void edge_rule_window(int pos, int len, FL L, FC C, F
 #pragma unroll
     for (int i = 0; i < 5; i++) {
         const int s = pos - 2 + i;
-        any |= s >= 0 && s + 1 < len && Lw[i] != Lw[i + 1];
+        any |= (INTERIOR || (s >= 0 && s + 1 < len)) && Lw[i] != Lw[i + 1];
     }
     out_label = Lw[2];
     if (!__builtin_amdgcn_ballot_w64(any)) {       // no lane of the wavefront is near a depth-label boundary
@@ -109,13 +113,13 @@ __device__ __forceinline__ void edge_rule_window(int pos, int len, FL L, FC C, F
 #pragma unroll
     for (int si = 4; si >= 0; si--) {              // s = pos + 2 ... pos - 2: the last writer is met first
         const int s = pos - 2 + si;
-        const bool boundary = s >= 0 && s + 1 < len && Lw[si] != Lw[si + 1];
+        const bool boundary = (INTERIOR || (s >= 0 && s + 1 < len)) && Lw[si] != Lw[si + 1];
         const int32_t cur = Cw[si + HALF];
         int branch = 0, dist = 0;
 #pragma unroll
         for (int d = 1; d <= HALF; d++) {          // left candidate first (.cu:25-55)
-            const bool left = s - d >= 0 && Cw[si + HALF - d] != cur;
-            const bool right = s + d < len && Cw[si + HALF + d] != cur;
+            const bool left = (INTERIOR || s - d >= 0) && Cw[si + HALF - d] != cur;
+            const bool right = (INTERIOR || s + d < len) && Cw[si + HALF + d] != cur;
             const bool open = branch == 0;
             dist = (open && (left || right)) ? d : dist;
             branch = open ? (left ? 1 : (right ? 2 : 0)) : branch;
@@ -174,65 +178,102 @@ __global__ __launch_bounds__(256) void edge_phase_kernel(int width, int height, 
 // K9, both phases in ONE launch.  The rule is a chain of dependent reads along the scan line, so it runs on LDS:
 // a workgroup stages depth labels / colour labels / depth of its 64 x 16 output tile plus a halo of
 // H = window/2 + 3 on every side, evaluates the horizontal phase for the tile's columns on all 16 + 2H rows
-// into LDS (the vertical phase of the tile reads exactly those), then the vertical phase from LDS to global
+// in place in LDS (the vertical phase of the tile reads exactly those), then the vertical phase from LDS to global
 // memory.  Same snapshot semantics as two launches (D2); the horizontal result never travels through HBM.
 // -------------------------------------------------------------------------------------------------
 constexpr int kEdgeTX = 64, kEdgeTY = 16;
 
 template <int HALF>
-__global__ __launch_bounds__(256) void edge_fused_kernel(int width, int height, int window,
+__global__ __launch_bounds__(256) void edge_fused_kernel(int width, int height,
                                                         const int32_t* __restrict__ color_labels,
                                                         const int32_t* __restrict__ L0, const float* __restrict__ D0,
                                                         int32_t* __restrict__ L2, float* __restrict__ D2)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char edge_smem[];
-    const int half = window / 2, H = half + 3;
-    const int EW = kEdgeTX + 2 * H, EH = kEdgeTY + 2 * H;
-    int32_t* sL = reinterpret_cast<int32_t*>(edge_smem);          // [EH][EW] inputs
-    int32_t* sC = sL + EW * EH;
-    float* sD = reinterpret_cast<float*>(sC + EW * EH);
-    int32_t* sL1 = reinterpret_cast<int32_t*>(sD + EW * EH);      // [EH][64] horizontal-phase result
-    float* sD1 = reinterpret_cast<float*>(sL1 + kEdgeTX * EH);
+    constexpr int H = HALF + 3;
+    constexpr int EW = kEdgeTX + 2 * H, EH = kEdgeTY + 2 * H, N = EW * EH;
+    __shared__ int32_t sL[N];                    // [EH][EW] inputs; the horizontal result replaces the tile's columns
+    __shared__ int32_t sC[N];
+    __shared__ float sD[N];
 
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * kEdgeTX, y0 = blockIdx.y * kEdgeTY;
-    for (int i = tid; i < EW * EH; i += 256) {
-        const int r = i / EW, c = i - r * EW;
-        const int gx = x0 - H + c, gy = y0 - H + r;
-        int32_t l = 0, cl = 0;
-        float d = 0.0f;
-        if (gx >= 0 && gx < width && gy >= 0 && gy < height) {
-            const size_t q = (size_t)gy * width + gx;
-            l = L0[q];
-            cl = color_labels[q];
-            d = D0[q];
+    {
+        // Staging.  Every load is issued before the first one is consumed: addresses are clamped into the image
+        // (always valid) and out-of-image elements are zeroed afterwards.  The 64 tile columns go row by row (one
+        // wavefront = one 256-byte row segment), the 2 x H halo columns 16 rows at a time; no index division anywhere.
+        static_assert(EH % 4 == 0 && EH <= 32 && 2 * H <= 16, "staging rounds");
+        constexpr int MR = EH / 4;
+        const int mc = tid & 63, mr = tid >> 6;
+        const int mcx = min(x0 + mc, width - 1);
+        const int hi = tid & 15, hrow = tid >> 4;
+        const int hcol = hi < H ? hi : (hi < 2 * H ? kEdgeTX + hi : EW - 1);     // staged column of this lane's halo element
+        const int hgx = x0 - H + hcol, hcx = min(max(hgx, 0), width - 1);
+        int32_t rl[MR + 2], rc[MR + 2];
+        float rd[MR + 2];
+#pragma unroll
+        for (int k = 0; k < MR + 2; k++) {
+            const int r = k < MR ? mr + 4 * k : min(hrow + 16 * (k - MR), EH - 1);
+            const int cy = min(max(y0 - H + r, 0), height - 1);
+            const size_t q = (size_t)cy * width + (k < MR ? mcx : hcx);
+            rl[k] = L0[q];
+            rc[k] = color_labels[q];
+            rd[k] = D0[q];
         }
-        sL[i] = l;
-        sC[i] = cl;
-        sD[i] = d;
+#pragma unroll
+        for (int k = 0; k < MR + 2; k++) {
+            const int r = k < MR ? mr + 4 * k : hrow + 16 * (k - MR);
+            const int gy = y0 - H + r;
+            const int gx = k < MR ? x0 + mc : hgx;
+            const bool in = gx >= 0 && gx < width && gy >= 0 && gy < height;
+            const bool mine = k < MR || (hi < 2 * H && r < EH);
+            if (mine) {
+                const int i = r * EW + (k < MR ? H + mc : hcol);
+                sL[i] = in ? rl[k] : 0;
+                sC[i] = in ? rc[k] : 0;
+                sD[i] = in ? rd[k] : 0.0f;
+            }
+        }
     }
     __syncthreads();
 
-    // horizontal phase: scan position = global x, line = staged row r
-    for (int i = tid; i < kEdgeTX * EH; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const int gx = x0 + c, gy = y0 - H + r;
+    // horizontal phase: scan position = global x, line = staged row r.  A wavefront takes a block of 16 columns x 4
+    // rows per round (not 64 x 1): superpixels are wider than 16 pixels, so most blocks see no depth-label boundary
+    // along x and leave through the rule's wavefront-uniform early exit.  Results wait in registers until every
+    // wavefront has read its inputs, then replace the tile's columns in place.
+    static_assert(EH % 4 == 0 && kEdgeTX == 64, "block mapping of the horizontal phase");
+    constexpr int HROUNDS = EH / 4;
+    const bool inner_x = x0 - 2 - HALF >= 0 && x0 + kEdgeTX + 2 + HALF < width;    // workgroup-uniform
+    const int hc = (tid >> 6) * 16 + (tid & 15), hr = (tid >> 4) & 3;
+    int32_t hl[HROUNDS];
+    float hd[HROUNDS];
+#pragma unroll
+    for (int k = 0; k < HROUNDS; k++) {
+        const int r = 4 * k + hr;
+        const int gx = x0 + hc, gy = y0 - H + r;
+        hl[k] = 0;
+        hd[k] = 0.0f;
         if (gx >= width || gy < 0 || gy >= height) continue;
         const int rb = r * EW + H - x0;                            // staged index of scan position k is rb + k
-        int32_t ol;
-        float od;
-        if (HALF > 0)
-            edge_rule_window<HALF>(gx, width, [&](int k) { return sL[rb + k]; }, [&](int k) { return sC[rb + k]; },
-                                   [&](int k) { return sD[rb + k]; }, ol, od);
-        else
-            edge_rule(gx, width, half, [&](int k) { return sL[rb + k]; }, [&](int k) { return sC[rb + k]; },
-                      [&](int k) { return sD[rb + k]; }, ol, od);
-        sL1[i] = ol;
-        sD1[i] = od;
+        auto fl = [&](int k) { return sL[rb + k]; };
+        auto fc = [&](int k) { return sC[rb + k]; };
+        auto fd = [&](int k) { return sD[rb + k]; };
+        if (inner_x) edge_rule_window<HALF, true>(gx, width, fl, fc, fd, hl[k], hd[k]);
+        else edge_rule_window<HALF, false>(gx, width, fl, fc, fd, hl[k], hd[k]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < HROUNDS; k++) {
+        const int r = 4 * k + hr;
+        const int gx = x0 + hc, gy = y0 - H + r;
+        if (gx >= width || gy < 0 || gy >= height) continue;
+        sL[r * EW + H + hc] = hl[k];
+        sD[r * EW + H + hc] = hd[k];
     }
     __syncthreads();
 
     // vertical phase on the horizontal result: scan position = global y, line = column c
+    const bool inner_y = y0 - 2 - HALF >= 0 && y0 + kEdgeTY + 2 + HALF < height;
+#pragma unroll
     for (int i = tid; i < kEdgeTX * kEdgeTY; i += 256) {
         const int ry = i >> 6, c = i & 63;
         const int gx = x0 + c, gy = y0 + ry;
@@ -240,14 +281,11 @@ __global__ __launch_bounds__(256) void edge_fused_kernel(int width, int height, 
         const int rr = H - y0;                                     // staged row of scan position k is rr + k
         int32_t ol;
         float od;
-        if (HALF > 0)
-            edge_rule_window<HALF>(gy, height, [&](int k) { return sL1[(rr + k) * kEdgeTX + c]; },
-                                   [&](int k) { return sC[(rr + k) * EW + c + H]; },
-                                   [&](int k) { return sD1[(rr + k) * kEdgeTX + c]; }, ol, od);
-        else
-            edge_rule(gy, height, half, [&](int k) { return sL1[(rr + k) * kEdgeTX + c]; },
-                      [&](int k) { return sC[(rr + k) * EW + c + H]; }, [&](int k) { return sD1[(rr + k) * kEdgeTX + c]; },
-                      ol, od);
+        auto fl = [&](int k) { return sL[(rr + k) * EW + c + H]; };
+        auto fc = [&](int k) { return sC[(rr + k) * EW + c + H]; };
+        auto fd = [&](int k) { return sD[(rr + k) * EW + c + H]; };
+        if (inner_y) edge_rule_window<HALF, true>(gy, height, fl, fc, fd, ol, od);
+        else edge_rule_window<HALF, false>(gy, height, fl, fc, fd, ol, od);
         const size_t q = (size_t)gy * width + gx;
         L2[q] = ol;
         D2[q] = od;
@@ -973,11 +1011,8 @@ int launch_ers_edge_refining(int width, int height, int window, const int32_t* c
     // The fused kernel's halo (window/2 + 3) and register window are laid out for the reference's window of 7
     // (EdgeRefinedSuperpixel.cpp:4); any other window runs the two-launch form, whose rule takes any reach.
     if (!two_launches && window / 2 == 3) {
-        const int H = window / 2 + 3;
-        const size_t ew = kEdgeTX + 2 * H, eh = kEdgeTY + 2 * H;
-        const size_t lds = ew * eh * 12 + (size_t)kEdgeTX * eh * 8;
         const dim3 grid(ceil_div(width, kEdgeTX), ceil_div(height, kEdgeTY));
-        hipLaunchKernelGGL(edge_fused_kernel<3>, grid, dim3(256), lds, s, width, height, window, color_labels, l0, d0, l2, d2);
+        hipLaunchKernelGGL(edge_fused_kernel<3>, grid, dim3(256), 0, s, width, height, color_labels, l0, d0, l2, d2);
         KDE_HIP_TRY(hipGetLastError());
         return KDE_OK;
     }
