@@ -175,11 +175,14 @@ __global__ __launch_bounds__(256) void edge_phase_kernel(int width, int height, 
 }
 
 // -------------------------------------------------------------------------------------------------
-// K9, both phases in ONE launch.  The rule is a chain of dependent reads along the scan line, so it runs on LDS:
-// a workgroup stages depth labels / colour labels / depth of its 64 x 16 output tile plus a halo of
-// H = window/2 + 3 on every side, evaluates the horizontal phase for the tile's columns on all 16 + 2H rows
-// in place in LDS (the vertical phase of the tile reads exactly those), then the vertical phase from LDS to global
-// memory.  Same snapshot semantics as two launches (D2); the horizontal result never travels through HBM.
+// K9, both phases in ONE launch.  The rule is a chain of dependent reads along the scan line, so it runs on LDS.
+// Around `pos` it reads colour labels at pos - 2 - HALF ... pos + 2 + HALF, depth labels at pos - 2 ... pos + 3 and
+// depths at pos - 2 ... pos + 1.  A workgroup owns a 64 x 16 output tile and stages
+//   colour labels : tile + (2 + HALF) on every side          (both phases search them),
+//   depth labels, depth : tile + 2 before / 3 after          (horizontal phase input along x, its result along y),
+// evaluates the horizontal phase for the tile's columns on the 16 + 5 rows the vertical phase will read, in place,
+// then the vertical phase from LDS to global memory.  Same snapshot semantics as two launches (D2); the horizontal
+// result never travels through HBM.  20 KB of LDS: 8 workgroups per CU, the whole 1080p grid is resident at once.
 // -------------------------------------------------------------------------------------------------
 constexpr int kEdgeTX = 64, kEdgeTY = 16;
 
@@ -189,49 +192,74 @@ __global__ __launch_bounds__(256) void edge_fused_kernel(int width, int height,
                                                         const int32_t* __restrict__ L0, const float* __restrict__ D0,
                                                         int32_t* __restrict__ L2, float* __restrict__ D2)
 {
-    constexpr int H = HALF + 3;
-    constexpr int EW = kEdgeTX + 2 * H, EH = kEdgeTY + 2 * H, N = EW * EH;
-    __shared__ int32_t sL[N];                    // [EH][EW] inputs; the horizontal result replaces the tile's columns
-    __shared__ int32_t sC[N];
-    __shared__ float sD[N];
+    constexpr int HC = 2 + HALF;                               // colour-label halo
+    constexpr int LA = 2, LB = 3;                              // depth-label / depth halo before / after
+    constexpr int CW = kEdgeTX + 2 * HC, CH = kEdgeTY + 2 * HC, CP = 80;       // pitch 80: rows 16 banks apart
+    constexpr int LW = kEdgeTX + LA + LB, LH = kEdgeTY + LA + LB, LP = LW + 1;
+    static_assert(CP >= CW && kEdgeTX == 64 && 2 * HC <= 16 && LA + LB <= 8 && CH <= 32 && LH <= 32, "staging layout");
+    __shared__ int32_t sC[CH * CP];
+    __shared__ int32_t sL[LH * LP];              // the horizontal result replaces the tile's columns
+    __shared__ float sD[LH * LP];
 
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * kEdgeTX, y0 = blockIdx.y * kEdgeTY;
     {
         // Staging.  Every load is issued before the first one is consumed: addresses are clamped into the image
         // (always valid) and out-of-image elements are zeroed afterwards.  The 64 tile columns go row by row (one
-        // wavefront = one 256-byte row segment), the 2 x H halo columns 16 rows at a time; no index division anywhere.
-        static_assert(EH % 4 == 0 && EH <= 32 && 2 * H <= 16, "staging rounds");
-        constexpr int MR = EH / 4;
+        // wavefront = one 256-byte row segment), the halo columns many rows at a time; no index division anywhere.
+        constexpr int CR = (CH + 3) / 4, LR = (LH + 3) / 4;   // rounds of 4 rows
         const int mc = tid & 63, mr = tid >> 6;
         const int mcx = min(x0 + mc, width - 1);
-        const int hi = tid & 15, hrow = tid >> 4;
-        const int hcol = hi < H ? hi : (hi < 2 * H ? kEdgeTX + hi : EW - 1);     // staged column of this lane's halo element
-        const int hgx = x0 - H + hcol, hcx = min(max(hgx, 0), width - 1);
-        int32_t rl[MR + 2], rc[MR + 2];
-        float rd[MR + 2];
+        const int chi = tid & 15, chrow = tid >> 4;            // colour halo: 16 rows per round, 2*HC of 16 lanes
+        const int chcol = chi < HC ? chi : (chi < 2 * HC ? kEdgeTX + chi : CW - 1);
+        const int chcx = min(max(x0 - HC + chcol, 0), width - 1);
+        const int lhi = tid & 7, lhrow = tid >> 3;             // label / depth halo: 32 rows in one round, LA+LB of 8 lanes
+        const int lhcol = lhi < LA ? lhi : (lhi < LA + LB ? kEdgeTX + lhi : LW - 1);
+        const int lhcx = min(max(x0 - LA + lhcol, 0), width - 1);
+        auto row_c = [&](int r) { return (size_t)min(max(y0 - HC + r, 0), height - 1) * width; };
+        auto row_l = [&](int r) { return (size_t)min(max(y0 - LA + r, 0), height - 1) * width; };
+        int32_t rc[CR + 2], rl[LR + 1];
+        float rd[LR + 1];
 #pragma unroll
-        for (int k = 0; k < MR + 2; k++) {
-            const int r = k < MR ? mr + 4 * k : min(hrow + 16 * (k - MR), EH - 1);
-            const int cy = min(max(y0 - H + r, 0), height - 1);
-            const size_t q = (size_t)cy * width + (k < MR ? mcx : hcx);
+        for (int k = 0; k < CR; k++) rc[k] = color_labels[row_c(min(mr + 4 * k, CH - 1)) + mcx];
+#pragma unroll
+        for (int k = 0; k < 2; k++) rc[CR + k] = color_labels[row_c(min(chrow + 16 * k, CH - 1)) + chcx];
+#pragma unroll
+        for (int k = 0; k < LR; k++) {
+            const size_t q = row_l(min(mr + 4 * k, LH - 1)) + mcx;
             rl[k] = L0[q];
-            rc[k] = color_labels[q];
             rd[k] = D0[q];
         }
+        {
+            const size_t q = row_l(min(lhrow, LH - 1)) + lhcx;
+            rl[LR] = L0[q];
+            rd[LR] = D0[q];
+        }
+        auto in_x = [&](int gx) { return gx >= 0 && gx < width; };
+        auto in_y = [&](int gy) { return gy >= 0 && gy < height; };
 #pragma unroll
-        for (int k = 0; k < MR + 2; k++) {
-            const int r = k < MR ? mr + 4 * k : hrow + 16 * (k - MR);
-            const int gy = y0 - H + r;
-            const int gx = k < MR ? x0 + mc : hgx;
-            const bool in = gx >= 0 && gx < width && gy >= 0 && gy < height;
-            const bool mine = k < MR || (hi < 2 * H && r < EH);
-            if (mine) {
-                const int i = r * EW + (k < MR ? H + mc : hcol);
-                sL[i] = in ? rl[k] : 0;
-                sC[i] = in ? rc[k] : 0;
-                sD[i] = in ? rd[k] : 0.0f;
+        for (int k = 0; k < CR; k++) {
+            const int r = mr + 4 * k;
+            if (r < CH) sC[r * CP + HC + mc] = (in_x(x0 + mc) && in_y(y0 - HC + r)) ? rc[k] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int r = chrow + 16 * k;
+            if (chi < 2 * HC && r < CH) sC[r * CP + chcol] = (in_x(x0 - HC + chcol) && in_y(y0 - HC + r)) ? rc[CR + k] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < LR; k++) {
+            const int r = mr + 4 * k;
+            if (r < LH) {
+                const bool in = in_x(x0 + mc) && in_y(y0 - LA + r);
+                sL[r * LP + LA + mc] = in ? rl[k] : 0;
+                sD[r * LP + LA + mc] = in ? rd[k] : 0.0f;
             }
+        }
+        if (lhi < LA + LB && lhrow < LH) {
+            const bool in = in_x(x0 - LA + lhcol) && in_y(y0 - LA + lhrow);
+            sL[lhrow * LP + lhcol] = in ? rl[LR] : 0;
+            sD[lhrow * LP + lhcol] = in ? rd[LR] : 0.0f;
         }
     }
     __syncthreads();
@@ -240,23 +268,22 @@ __global__ __launch_bounds__(256) void edge_fused_kernel(int width, int height,
     // rows per round (not 64 x 1): superpixels are wider than 16 pixels, so most blocks see no depth-label boundary
     // along x and leave through the rule's wavefront-uniform early exit.  Results wait in registers until every
     // wavefront has read its inputs, then replace the tile's columns in place.
-    static_assert(EH % 4 == 0 && kEdgeTX == 64, "block mapping of the horizontal phase");
-    constexpr int HROUNDS = EH / 4;
-    const bool inner_x = x0 - 2 - HALF >= 0 && x0 + kEdgeTX + 2 + HALF < width;    // workgroup-uniform
+    constexpr int HROUNDS = (LH + 3) / 4;
+    const bool inner_x = x0 - HC >= 0 && x0 + kEdgeTX + HC < width;                 // workgroup-uniform
     const int hc = (tid >> 6) * 16 + (tid & 15), hr = (tid >> 4) & 3;
     int32_t hl[HROUNDS];
     float hd[HROUNDS];
 #pragma unroll
     for (int k = 0; k < HROUNDS; k++) {
-        const int r = 4 * k + hr;
-        const int gx = x0 + hc, gy = y0 - H + r;
+        const int r = 4 * k + hr;                                  // row of the label / depth planes
+        const int gx = x0 + hc, gy = y0 - LA + r;
         hl[k] = 0;
         hd[k] = 0.0f;
-        if (gx >= width || gy < 0 || gy >= height) continue;
-        const int rb = r * EW + H - x0;                            // staged index of scan position k is rb + k
-        auto fl = [&](int k) { return sL[rb + k]; };
-        auto fc = [&](int k) { return sC[rb + k]; };
-        auto fd = [&](int k) { return sD[rb + k]; };
+        if (r >= LH || gx >= width || gy < 0 || gy >= height) continue;
+        const int lb = r * LP + LA - x0, cb = (r + HC - LA) * CP + HC - x0;       // staged index of scan position k is base + k
+        auto fl = [&](int k) { return sL[lb + k]; };
+        auto fc = [&](int k) { return sC[cb + k]; };
+        auto fd = [&](int k) { return sD[lb + k]; };
         if (inner_x) edge_rule_window<HALF, true>(gx, width, fl, fc, fd, hl[k], hd[k]);
         else edge_rule_window<HALF, false>(gx, width, fl, fc, fd, hl[k], hd[k]);
     }
@@ -264,26 +291,25 @@ __global__ __launch_bounds__(256) void edge_fused_kernel(int width, int height,
 #pragma unroll
     for (int k = 0; k < HROUNDS; k++) {
         const int r = 4 * k + hr;
-        const int gx = x0 + hc, gy = y0 - H + r;
-        if (gx >= width || gy < 0 || gy >= height) continue;
-        sL[r * EW + H + hc] = hl[k];
-        sD[r * EW + H + hc] = hd[k];
+        const int gx = x0 + hc, gy = y0 - LA + r;
+        if (r >= LH || gx >= width || gy < 0 || gy >= height) continue;
+        sL[r * LP + LA + hc] = hl[k];
+        sD[r * LP + LA + hc] = hd[k];
     }
     __syncthreads();
 
     // vertical phase on the horizontal result: scan position = global y, line = column c
-    const bool inner_y = y0 - 2 - HALF >= 0 && y0 + kEdgeTY + 2 + HALF < height;
+    const bool inner_y = y0 - HC >= 0 && y0 + kEdgeTY + HC < height;
 #pragma unroll
     for (int i = tid; i < kEdgeTX * kEdgeTY; i += 256) {
         const int ry = i >> 6, c = i & 63;
         const int gx = x0 + c, gy = y0 + ry;
         if (gx >= width || gy >= height) continue;
-        const int rr = H - y0;                                     // staged row of scan position k is rr + k
+        auto fl = [&](int k) { return sL[(k - y0 + LA) * LP + LA + c]; };
+        auto fc = [&](int k) { return sC[(k - y0 + HC) * CP + HC + c]; };
+        auto fd = [&](int k) { return sD[(k - y0 + LA) * LP + LA + c]; };
         int32_t ol;
         float od;
-        auto fl = [&](int k) { return sL[(rr + k) * EW + c + H]; };
-        auto fc = [&](int k) { return sC[(rr + k) * EW + c + H]; };
-        auto fd = [&](int k) { return sD[(rr + k) * EW + c + H]; };
         if (inner_y) edge_rule_window<HALF, true>(gy, height, fl, fc, fd, ol, od);
         else edge_rule_window<HALF, false>(gy, height, fl, fc, fd, ol, od);
         const size_t q = (size_t)gy * width + gx;
