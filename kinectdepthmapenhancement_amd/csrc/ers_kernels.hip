@@ -10,6 +10,7 @@
 // reach = window/2 - 1 (descending = last writer first); reach = 2 for the reference's window of 7.
 // K10 reads the K9 result and writes a separate buffer (D3).
 #include "kde_internal.h"
+#include "kde_device_math.h"
 
 namespace kde {
 namespace {
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(kThreads) void enhance_kernel(EnhDev a)
                 float filter = ss[i * a.window + j];
                 if (color_sigma != 0.0f) {
                     const float xarg = (float)color_dist2(cc, sc[li]) / den0;
-                    if (!(xarg >= a.exp_zero)) filter *= expf(-xarg);
+                    if (!(xarg >= a.exp_zero)) filter *= exp_denormal(-xarg);
                 }
                 w_average += dq * filter;
                 weight += filter;
@@ -438,12 +439,12 @@ __global__ __launch_bounds__(kThreads) void enhance_kernel(EnhDev a)
                         else color_sigma *= 0.3f;
                         // den may underflow to 0: cd/0 = inf -> factor skipped; 0/0 = NaN -> NaN result (Q6)
                         const float xarg = (float)color_dist2(cc, sc[li]) / (2 * (color_sigma * color_sigma));
-                        if (!(xarg >= a.exp_zero)) filter *= expf(-xarg);
+                        if (!(xarg >= a.exp_zero)) filter *= exp_denormal(-xarg);
                     }
                     if (a.depth_sigma != 0.0f) {
                         const float dd = dq - w_average;
                         const float xd = (dd * dd) / dden;
-                        if (!(xd >= a.exp_zero)) filter *= expf(-xd);
+                        if (!(xd >= a.exp_zero)) filter *= exp_denormal(-xd);
                     }
                     numerator += dq * filter;
                     denominator += filter;

@@ -6,6 +6,7 @@
 // tiles (+halo) are staged once in LDS, out-of-image and invalid (<= 50 mm) taps are stored as
 // depth 0 so the inner loops carry no bounds tests.  No MFMA: this is a stencil.
 #include "kde_internal.h"
+#include "kde_device_math.h"
 
 namespace kde {
 namespace {
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void jbf_generic_kernel(JbfDev a)
             if (dq > 50.0f) {
                 const int cd = color_dist2(cc, sc[li]);
                 float filter = ss[i * a.window + j];
-                if (a.color_on && cd < a.cd_skip) filter *= expf(-(float)cd / a.color_den);
+                if (a.color_on && cd < a.cd_skip) filter *= exp_denormal(-(float)cd / a.color_den);
                 w_average += dq * filter;
                 weight += filter;
             }
@@ -117,11 +118,11 @@ __global__ __launch_bounds__(kThreads) void jbf_generic_kernel(JbfDev a)
                 if (dq > 50.0f) {
                     const int cd = color_dist2(cc, sc[li]);
                     float filter = ss[i * a.window + j];
-                    if (a.color_on && cd < a.cd_skip) filter *= expf(-(float)cd / a.color_den);
+                    if (a.color_on && cd < a.cd_skip) filter *= exp_denormal(-(float)cd / a.color_den);
                     const float dd = dq - w_average;
                     const float d2 = dd * dd;
                     // NaN d2 fails the '<' test on purpose: the reference multiplies the NaN in
-                    if (a.depth_on && !(d2 >= a.d2_skip)) filter *= expf(-d2 / a.depth_den);
+                    if (a.depth_on && !(d2 >= a.d2_skip)) filter *= exp_denormal(-d2 / a.depth_den);
                     numerator += dq * filter;
                     denominator += filter;
                 }
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(kThreads) void mrf_kernel(MrfDev a)
             if (dq > 50.0f) {
                 const int cd = color_dist2(cc, sc[li]);
                 float color_filter = 0.0f;
-                if (a.color_sigma != 0.0f) color_filter = expf(-a.color_sigma * (float)cd);
+                if (a.color_sigma != 0.0f) color_filter = exp_denormal(-a.color_sigma * (float)cd);
                 float filter = a.smooth_sigma;
                 filter *= color_filter;
                 numerator += dq * filter;

@@ -18,4 +18,16 @@ __device__ __forceinline__ float sqrt_int24(float x)
     return x == 0.0f ? 0.0f : r1;
 }
 
+// expf() for the reference-shaped kernels.  The reference's rule "a factor that underflowed to exactly 0 is skipped"
+//  is stated for an expf() that rounds to the binary32 denormal grid: 0 iff the true value is below 2^-150
+// (x < -150 ln 2 = -103.972).  The library expf() returns 0 as soon as the true value is below the smallest denormal
+// 2^-149 (x < -103.28), so a weight of half a unit to one unit of the grid would be lost.  Below -64 the argument is
+// shifted by 64 and the (normal) result multiplied by e^-64: that product is rounded to the denormal grid once.
+__device__ __forceinline__ float exp_denormal(float x)
+{
+    const bool shifted = x < -64.0f;
+    const float r = expf(shifted ? x + 64.0f : x);
+    return shifted ? r * 0x1.969d48p-93f : r;
+}
+
 }  // namespace kde

@@ -152,7 +152,8 @@ static inline float color_diff3(const uint8_t* a, const uint8_t* b)
  * 1e-4 against THIS float32 evaluation at such pixels, so the probe below says what any faithful evaluation
  * may return there: the binary64 value of the same formula with the reference's decisions, re-evaluated with
  *   - the first-pass average moved by +-eps (eps = the rounding a float32 sum of n_eff weights cannot avoid),
- *   - the depth-factor underflow threshold (x = 150 ln 2) moved by +-1.5e-4 relative,
+ *   - the depth-factor underflow threshold (x = 150 ln 2) moved by +-(1.5e-4 + the effect of +-eps on a tap at the
+ *     threshold) relative, independently of the average (see thr_band),
  *   - the float32 underflow-to-zero point of a whole weight (2^-150) moved by +-5e-4 relative,
  * the last two only where a tap actually sits inside such a band.  [lo, hi] spans the non-zero results (the
  * float32 restatement's own value included); flags say whether 0 is one of the admissible results.
@@ -180,12 +181,23 @@ static inline double quantised(double f, double d, double centre, int q)
     return g > 0.0 ? g : 0.0;
 }
 
+/* Half-width (relative, in x = (d - avg)^2 / dden) of the band around the depth-factor underflow point x = 150 ln 2 in
+ * which a tap's skip decision is open: 1.5e-4 for the rounding of x itself, plus what moving the average by the relative
+ * amount band_eps does to the x of a tap that sits at the threshold (|d - avg| = sqrt(x0 dden)).  Without the second
+ * term the envelope would sample the result at avg - eps, avg, avg + eps with the decision FOLLOWING the average, and miss
+ * everything an evaluation whose average lies in between can return just before the decision flips. */
+static inline double thr_band(double band_eps, double wa, double dden)
+{
+    return 1.5e-4 + (dden > 0.0 ? 2.0 * band_eps * fabs(wa) / sqrt(kXZ * dden) : 0.0);
+}
+
 /* both passes in binary64; returns the result (0 = "output is 0"), *band |= 1 when a tap sits in a decision band.
  * q1 / q2: quantisation allowance of the first / second pass weights around centre1 / centre2; den_out: the two sums
- * of weights (to tell whether the allowance can matter at all). */
+ * of weights (to tell whether the allowance can matter at all); band_eps: the relative uncertainty of the average the
+ * caller is going to probe (widens the threshold band, see thr_band); *tol_out: that band's half-width. */
 static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double avg_rel, double thr_scale,
                          double und_scale, int* band, double* n_eff, int q1, double centre1, int q2, double centre2,
-                         double* den_out)
+                         double* den_out, double band_eps, double* tol_out)
 {
     const double U = kUnder * und_scale;
     double wa = 0.0, wt = 0.0, wt2 = 0.0;
@@ -201,6 +213,8 @@ static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double av
     if (den_out) den_out[0] = wt, den_out[1] = 0.0;
     if (!(wt > 0.0)) return 0.0;
     if (n_eff) *n_eff = wt * wt / wt2;
+    const double tol = depth_on ? thr_band(band_eps, wa / wt, dden) : 1.5e-4;
+    if (tol_out) *tol_out = tol;
     wa = wa / wt * (1.0 + avg_rel);
     double nu = 0.0, de = 0.0;
     for (int k = 0; k < t->n; k++) {
@@ -208,7 +222,7 @@ static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double av
         if (f <= U) continue;
         if (depth_on) {
             const double xd = (t->d[k] - wa) * (t->d[k] - wa) / dden;
-            if (fabs(xd / kXZ - 1.0) <= 1.5e-4) *band |= 1;
+            if (fabs(xd / kXZ - 1.0) <= tol) *band |= 1;
             if (xd < kXZ * thr_scale) f *= exp(-xd);
             if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
             if (f <= U) continue;
@@ -326,21 +340,22 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                     }
                 int band = 0;
                 double n_eff = 1.0, dens[2] = {0.0, 0.0};
-                const double r0 = jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens);
+                double tol = 1.5e-4;
+                const double r0 = jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL);
                 /* rounding of a float32 sum grows with the number of taps that carry weight: the participation
                  * ratio (sum w)^2 / sum w^2; measured 25 ulps at 128 equal weights -> 2.5 sqrt(n_eff) */
                 const double eps_avg = (4.0 + 2.5 * sqrt(n_eff)) * 1.1920928955078125e-7;
                 env_add(&e, r0);
-                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL));
-                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, -eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL));
+                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol));
+                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, -eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol));
                 if (band) {
                     flag |= 2;
                     for (int a = -1; a <= 1; a++)
                         for (int b = -1; b <= 1; b++)
                             for (int c = -1; c <= 1; c++) {
                                 int dummy = 0;
-                                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, a * eps_avg, 1.0 + b * 1.5e-4,
-                                                       1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL));
+                                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, a * eps_avg, 1.0 + b * tol,
+                                                       1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL));
                             }
                 }
                 /* a sum of weights so small that the 2^-149 grid is within 1e-6 of it: the float32 value is
@@ -352,7 +367,7 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                         for (int b = (qb ? -1 : 0); b <= (qb ? 1 : 0); b++) {
                             if (a == 0 && b == 0) continue;
                             int dummy = 0;
-                            env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &dummy, NULL, a, wa0, b, r0, NULL));
+                            env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &dummy, NULL, a, wa0, b, r0, NULL, 0.0, NULL));
                         }
                 }
                 env_add(&e, (double)out);
@@ -914,7 +929,7 @@ typedef struct {
  * Returns the result (0 = "output is 0", NaN = the Q6 quirk); *band |= 1 when a tap sits in a decision band. */
 static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, int depth_on, float a, double avg_rel,
                          double thr_scale, double und_scale, int* band, double* n_eff, int q1, double centre1, int q2,
-                         double centre2, double* den_out)
+                         double centre2, double* den_out, double band_eps, double* tol_out)
 {
     const double U = kUnder * und_scale;
     double wa = 0.0, wt = 0.0, wt2 = 0.0;
@@ -933,6 +948,8 @@ static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, i
     if (den_out) den_out[0] = wt, den_out[1] = 0.0;
     if (!(wt > 0.0)) return 0.0;
     if (n_eff) *n_eff = wt * wt / wt2;
+    const double tol = depth_on ? thr_band(band_eps, wa / wt, dden) : 1.5e-4;     /* see jbf_eval64 */
+    if (tol_out) *tol_out = tol;
     wa = wa / wt * (1.0 + avg_rel);
     float cs = color_sigma_in;
     double nu = 0.0, de = 0.0;
@@ -947,7 +964,7 @@ static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, i
         }
         if (depth_on) {
             const double xd = (t->d[k] - wa) * (t->d[k] - wa) / dden;
-            if (fabs(xd / kXZ - 1.0) <= 1.5e-4) *band |= 1;
+            if (fabs(xd / kXZ - 1.0) <= tol) *band |= 1;
             if (xd < kXZ * thr_scale) f *= exp(-xd);
         }
         if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
@@ -1084,11 +1101,12 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                 }
                 int band = 0;
                 double n_eff = 1.0, dens[2] = {0.0, 0.0};
-                const double r0 = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens);
+                double tol = 1.5e-4;
+                const double r0 = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL);
                 const double eps_avg = (4.0 + 2.5 * sqrt(n_eff)) * 1.1920928955078125e-7;
                 for (int v = 0; v < nalt; v++)
                     for (int a = -1; a <= 1; a++) {
-                        const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL);
+                        const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol);
                         if (r != r) nan_ok = 1;
                         else env_add(&e, r);
                     }
@@ -1100,7 +1118,7 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                                 for (int c = -1; c <= 1; c++) {
                                     int dummy = 0;
                                     const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg,
-                                                                1.0 + b * 1.5e-4, 1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL);
+                                                                1.0 + b * tol, 1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL);
                                     if (r != r) nan_ok = 1;
                                     else env_add(&e, r);
                                 }
@@ -1112,7 +1130,7 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                         for (int b = (qb ? -1 : 0); b <= (qb ? 1 : 0); b++) {
                             if (a == 0 && b == 0) continue;
                             int dummy = 0;
-                            const double r = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &dummy, NULL, a, r0, b, r0, NULL);
+                            const double r = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &dummy, NULL, a, r0, b, r0, NULL, 0.0, NULL);
                             if (r != r) nan_ok = 1;
                             else env_add(&e, r);
                         }

@@ -186,6 +186,34 @@ def test_denormal_range_weights_are_kept(torch_cuda, F, oracle):
             assert_depth_close(got, ref, RTOL, ill=env, what=f"denormal weights, variant {nm} window {win}")
 
 
+def test_weights_of_the_last_denormal_unit_are_kept(torch_cuda, F, oracle):
+    """Found by the stress tool (seed 777, case 791).  A colour factor exp(-103.68) is 0.67 units of the float32 denormal
+    grid: expf rounds it to one unit, it is not "== 0", so it is multiplied in and the hole is filled.  The library
+    expf() on the device returns 0 below 2^-149 (x < -103.28), which lost such weights in the reference-shaped
+    (generic) kernel for 103.28 < x < 103.97; it now uses exp_denormal() (csrc/kde_device_math.h).
+    Scene: holes of colour (96,96,0) in a (224,224,224) frame, sigma_c 20 -> cd / 800 = 103.68 for every neighbour."""
+    h, w = 36, 44
+    rng = np.random.default_rng(5)
+    depth = (1800.0 + 20.0 * rng.random((h, w))).astype(np.float32)
+    bgr = np.full((h, w, 3), 224, np.uint8)
+    holes = [(y, x) for y in range(5, h - 5, 6) for x in range(5, w - 5, 6)]
+    for y, x in holes:
+        depth[y, x] = 0.0
+        bgr[y, x] = (96, 96, 0)
+    for win in (3, 5, 9, 11):
+        ref, env = oracle.jbf_kernel(depth, bgr, win, 70.0, 20.0, 1000.0, return_ill=True)
+        assert all(ref[y, x] > 1700.0 for y, x in holes)                # the reference fills these holes
+        assert all((env.flags[y, x] & oracle.Env.ZERO_OK) == 0 for y, x in holes)
+        for v, nm, vw in [(-1, "auto", win), (0, "generic", win)] + [t for t in _variant_windows(F) if t[2] == win]:
+            jbf = F.JointBilateralFilter(w, h, params(F, win, 70.0, 20.0, 1000.0, pre=0))
+            jbf.set_variant(v)
+            out = torch_cuda.empty((1, h, w), dtype=torch_cuda.float32, device="cuda")
+            jbf.filter_batch(dev(torch_cuda, depth[None]), dev(torch_cuda, bgr[None]), out)
+            got = host(out)[0]
+            assert all(got[y, x] > 1700.0 for y, x in holes), f"variant {nm} window {win}: a one-unit weight was lost"
+            assert_depth_close(got, ref, RTOL, ill=env, what=f"last denormal unit, variant {nm} window {win}")
+
+
 @pytest.mark.parametrize("win", [11, 19])
 def test_rule_elision_bodies_all_match_the_oracle(torch_cuda, F, oracle, win):
     """K1's tuned kernels (windows >= 9) pick, per tile, a body without the colour and / or depth Q1 rule when the

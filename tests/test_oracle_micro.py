@@ -4,6 +4,7 @@ The reference ships no tests or golden vectors, so the oracle is
 (a) closed-form cases, (b) slow literal Python ports of the CUDA text written separately from
 oracle/kde_oracle.c, on tiny inputs."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -424,6 +425,24 @@ def test_envelope_flags_a_tap_on_the_q1_jump(oracle):
     p = (ys[0], xs[0])
     assert env.hi[p] - env.lo[p] > 1.0                 # skipped: the outlier pulls the result by ~ delta/25 = 12 mm
     assert abs(env.lo[p] - 1000.0) < 0.01 and env.hi[p] > 1010.0   # factor 1e-45: outlier ignored; skipped: it counts fully
+
+
+def test_envelope_spans_the_whole_sawtooth_next_to_a_q1_flip(oracle):
+    """Found by the stress tool (seed 777, case 700): window 19, sigma_d 5.  One tap sits at x = (d - avg)^2 / 50 = 103.957,
+    i.e. 1.4e-4 below the underflow point, and the near taps' weights exp(-(d - avg)^2 / 50) move by 0.3 % per 0.02 mm of
+    the average.  As the average falls from avg + eps to avg - eps the result slides from 905.3 down to ~898 and then jumps
+    to ~1255 when the tap's factor underflows and is skipped.  Sampling avg - eps, avg, avg + eps with the decision
+    following the average misses the lower part of the slide; the threshold band must be widened by what eps does to x
+    (oracle thr_band).  The three values the GPU kernels returned (packed, scalar, generic) lie on the slide."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "k1_band_sawtooth.npz"))
+    win, ss, cs, ds = z["params"]
+    ref, env = oracle.jbf_kernel(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds), return_ill=True)
+    c = (9, 9)
+    assert env.flags[c] & oracle.Env.BAND and env.flags[c] & oracle.Env.COND
+    assert env.lo[c] < 899.0 and env.hi[c] > 1255.0
+    for v in z["observed"]:
+        assert env.lo[c] <= v <= env.hi[c]
+    assert abs(ref[c] - 901.3955) < 1e-3
 
 
 def test_envelope_keeps_denormal_range_weights(oracle):
