@@ -151,7 +151,8 @@ static inline float color_diff3(const uint8_t* a, const uint8_t* b)
  * sigmas, ill-conditioned in its own first-pass average.  No float32 evaluation in another order can be held to
  * 1e-4 against THIS float32 evaluation at such pixels, so the probe below says what any faithful evaluation
  * may return there: the binary64 value of the same formula with the reference's decisions, re-evaluated with
- *   - the first-pass average moved by +-eps (eps = the rounding a float32 sum of n_eff weights cannot avoid),
+ *   - the first-pass average moved by +-eps (eps = the first-order bound of float32 summation over the taps that
+ *     can round the sum, see n_significant),
  *   - the depth-factor underflow threshold (x = 150 ln 2) moved by +-(1.5e-4 + the effect of +-eps on a tap at the
  *     threshold) relative, independently of the average (see thr_band),
  *   - the float32 underflow-to-zero point of a whole weight (2^-150) moved by +-5e-4 relative,
@@ -191,6 +192,21 @@ static inline double thr_band(double band_eps, double wa, double dden)
     return 1.5e-4 + (dden > 0.0 ? 2.0 * band_eps * fabs(wa) / sqrt(kXZ * dden) : 0.0);
 }
 
+/* Number of additions that can round when n weights are summed in float32: the taps whose weight is at least half
+ * an ulp of the total (smaller ones are absorbed, each costing at most its own size).  Recursive summation of n
+ * positive terms is off by at most (n - 1) * 2^-24 relative, i.e. (n - 1) / 2 ulps, and reaches a good part of
+ * that when many terms are EQUAL (quantised colours: every addition rounds the same way while the sum stays in one
+ * binade; measured 25 ulps at 128 equal weights, 30 ulps at 160 weights of 6 distinct values).  The participation
+ * ratio (sum w)^2 / sum w^2 used before underestimates this: a tap 100 times lighter than the heaviest still rounds
+ * the running sum by up to half an ulp. */
+static double n_significant(const double* w, const uint8_t* use, int n, double total, double under)
+{
+    int c = 0;
+    for (int k = 0; k < n; k++)
+        if ((!use || use[k]) && w[k] > under && w[k] >= total * 0x1p-24) c++;
+    return (double)c;
+}
+
 /* both passes in binary64; returns the result (0 = "output is 0"), *band |= 1 when a tap sits in a decision band.
  * q1 / q2: quantisation allowance of the first / second pass weights around centre1 / centre2; den_out: the two sums
  * of weights (to tell whether the allowance can matter at all); band_eps: the relative uncertainty of the average the
@@ -200,7 +216,7 @@ static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double av
                          double* den_out, double band_eps, double* tol_out)
 {
     const double U = kUnder * und_scale;
-    double wa = 0.0, wt = 0.0, wt2 = 0.0;
+    double wa = 0.0, wt = 0.0;
     for (int k = 0; k < t->n; k++) {
         double f = t->base[k];
         if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
@@ -208,11 +224,10 @@ static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double av
         else f = quantised(f, t->d[k], centre1, q1);
         wa += t->d[k] * f;
         wt += f;
-        wt2 += f * f;
     }
     if (den_out) den_out[0] = wt, den_out[1] = 0.0;
     if (!(wt > 0.0)) return 0.0;
-    if (n_eff) *n_eff = wt * wt / wt2;
+    if (n_eff) *n_eff = n_significant(t->base, NULL, t->n, wt, U);
     const double tol = depth_on ? thr_band(band_eps, wa / wt, dden) : 1.5e-4;
     if (tol_out) *tol_out = tol;
     wa = wa / wt * (1.0 + avg_rel);
@@ -342,9 +357,9 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                 double n_eff = 1.0, dens[2] = {0.0, 0.0};
                 double tol = 1.5e-4;
                 const double r0 = jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL);
-                /* rounding of a float32 sum grows with the number of taps that carry weight: the participation
-                 * ratio (sum w)^2 / sum w^2; measured 25 ulps at 128 equal weights -> 2.5 sqrt(n_eff) */
-                const double eps_avg = (4.0 + 2.5 * sqrt(n_eff)) * 1.1920928955078125e-7;
+                /* rounding of the float32 sums behind the average: the first-order bound of recursive summation over
+                 * the taps that can round at all (see n_significant), plus the products and the division */
+                const double eps_avg = (4.0 + 0.5 * n_eff) * 1.1920928955078125e-7;
                 env_add(&e, r0);
                 env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol));
                 env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, -eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol));
@@ -373,7 +388,7 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                 env_add(&e, (double)out);
                 if (e.nonzero) {
                     const double mid = r0 != 0.0 ? r0 : e.lo;
-                    if (e.hi - e.lo > 2e-5 * fabs(mid)) flag |= 4;
+                    if (e.hi - e.lo > 5e-5 * fabs(mid)) flag |= 4;
                 } else {
                     e.lo = e.hi = 0.0;
                 }
@@ -932,8 +947,10 @@ static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, i
                          double centre2, double* den_out, double band_eps, double* tol_out)
 {
     const double U = kUnder * und_scale;
-    double wa = 0.0, wt = 0.0, wt2 = 0.0;
+    double wa = 0.0, wt = 0.0;
+    double w1[OKDE_MAXTAPS];
     for (int k = 0; k < t->n; k++) {
+        w1[k] = 0.0;
         if (!t->same[k]) continue;
         double f = t->s[k];
         if (color_sigma_in != 0.0f && expf(-t->cd[k] / (2 * (color_sigma_in * color_sigma_in))) != 0.0f)
@@ -941,13 +958,13 @@ static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, i
         if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
         if (f <= U) f = 0.0;
         else f = quantised(f, t->d[k], centre1, q1);
+        w1[k] = f;
         wa += t->d[k] * f;
         wt += f;
-        wt2 += f * f;
     }
     if (den_out) den_out[0] = wt, den_out[1] = 0.0;
     if (!(wt > 0.0)) return 0.0;
-    if (n_eff) *n_eff = wt * wt / wt2;
+    if (n_eff) *n_eff = n_significant(w1, NULL, t->n, wt, 0.0);
     const double tol = depth_on ? thr_band(band_eps, wa / wt, dden) : 1.5e-4;     /* see jbf_eval64 */
     if (tol_out) *tol_out = tol;
     wa = wa / wt * (1.0 + avg_rel);
@@ -1103,7 +1120,7 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                 double n_eff = 1.0, dens[2] = {0.0, 0.0};
                 double tol = 1.5e-4;
                 const double r0 = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL);
-                const double eps_avg = (4.0 + 2.5 * sqrt(n_eff)) * 1.1920928955078125e-7;
+                const double eps_avg = (4.0 + 0.5 * n_eff) * 1.1920928955078125e-7;     /* as in okde_jbf_kernel */
                 for (int v = 0; v < nalt; v++)
                     for (int a = -1; a <= 1; a++) {
                         const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol);
@@ -1139,7 +1156,7 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                 else env_add(&e, (double)result);
                 if (e.nonzero) {
                     const double mid = (r0 == r0 && r0 != 0.0) ? r0 : e.lo;
-                    if (e.hi - e.lo > 2e-5 * fabs(mid)) flag |= 4;
+                    if (e.hi - e.lo > 5e-5 * fabs(mid)) flag |= 4;
                 } else {
                     e.lo = e.hi = 0.0;
                 }

@@ -57,7 +57,7 @@ void okde_cv_bilateral_8uc3(const uint8_t* src, int width, int height, size_t sr
  * share; the float32 restatement's own value is included.  flags:
  *   bit 1 (2)  a tap sits on a Q1 decision (depth-factor underflow at x = 150 ln 2, or a whole weight at the
  *              float32 underflow-to-zero point 2^-150): both outcomes are in [lo, hi]
- *   bit 2 (4)  [lo, hi] is wider than 2e-5 relative (rounding of the average amplified, or the float32 value itself
+ *   bit 2 (4)  [lo, hi] is wider than 5e-5 relative, half the 1e-4 tolerance (rounding of the average amplified, or the float32 value itself
  *              is denormal-quantisation noise): the pixel is compared with the envelope instead of the float32 value
  *   bit 3 (8)  0 is one of the admissible results (lo = hi = 0 when it is the only one)
  *   bit 4 (16) NaN is one of the admissible results (K10's 0/0 quirk Q6 next to a deviation of one rounding error)

@@ -76,7 +76,7 @@ def assert_depth_close(got, ref, rtol=1e-4, ill=None, max_bad=0, what="depth", m
       * pixels the oracle's envelope does not flag (and all pixels when no envelope is given): identical zero / NaN
         mask and <= rtol relative error against the float32 restatement;
       * flagged pixels (oracle.Env: a tap on a Q1 decision, or the pixel amplifies the rounding of its own first-pass
-        average beyond 2e-5): the value must lie inside the envelope [lo, hi] of binary64 evaluations of the same
+        average beyond 5e-5): the value must lie inside the envelope [lo, hi] of binary64 evaluations of the same
         formula (widened by rtol), or be 0 / NaN where the envelope admits that.
     Returns the max relative error on unflagged pixels; per-class counts and the max error on flagged pixels are
     logged (PARITY_LOG) and `max_flagged` bounds the flagged fraction."""

