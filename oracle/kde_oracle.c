@@ -194,11 +194,9 @@ static inline double thr_band(double band_eps, double wa, double dden)
 
 /* Number of additions that can round when n weights are summed in float32: the taps whose weight is at least half
  * an ulp of the total (smaller ones are absorbed, each costing at most its own size).  Recursive summation of n
- * positive terms is off by at most (n - 1) * 2^-24 relative, i.e. (n - 1) / 2 ulps, and reaches a good part of
- * that when many terms are EQUAL (quantised colours: every addition rounds the same way while the sum stays in one
- * binade; measured 25 ulps at 128 equal weights, 30 ulps at 160 weights of 6 distinct values).  The participation
- * ratio (sum w)^2 / sum w^2 used before underestimates this: a tap 100 times lighter than the heaviest still rounds
- * the running sum by up to half an ulp. */
+ * positive terms is off by at most (n - 1) * 2^-24 relative, i.e. (n - 1) / 2 ulps.  The participation ratio
+ * (sum w)^2 / sum w^2 used before under-counts: a tap 100 times lighter than the heaviest still rounds the running
+ * sum by up to half an ulp (measured: 29 ulps on the average of 345 taps, 160 of them significant, ratio 41). */
 static double n_significant(const double* w, const uint8_t* use, int n, double total, double under)
 {
     int c = 0;

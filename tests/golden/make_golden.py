@@ -9,7 +9,8 @@ What is pinned: the CPU oracle's outputs (oracle/kde_oracle.c) on
     full-frame outputs.
 k1_band_sawtooth.npz is not written by this script: it is the 19x19 neighbourhood of one pixel of a generated
 stress case (python tools/stress_parity.py --seed 777 --cases 800 --dump DIR -> case700_k1.npz, rows 16..34,
-columns 90..108) plus the three values the GPU kernels returned there; tests/test_oracle_micro.py explains it.
+columns 90..108) plus the three values the GPU kernels returned there; k1_sum_bound.npz likewise (--seed 11 --cases
+4000 -> case1455_k1.npz, rows 1..19, columns 68..86); tests/test_oracle_micro.py explains both.
 The reference itself cannot be built or run here, so these vectors pin the
 restatement, not the CUDA binary: parity stays "unpinned" with respect to the reference.
 """

@@ -445,6 +445,31 @@ def test_envelope_spans_the_whole_sawtooth_next_to_a_q1_flip(oracle):
     assert abs(ref[c] - 901.3955) < 1e-3
 
 
+def test_envelope_allows_the_summation_error_of_every_tap_that_can_round(oracle):
+    """Found by the stress tool (seeds 11 / 22 / 44): window 19, sigma_s 0.5 (most of the spatial table underflows, so
+    those taps carry the bare colour factor), quantised colours, sigma_d 5.  345 valid taps, 160 of them heavy enough
+    to round the running sum, but a participation ratio (sum w)^2 / sum w^2 of only 41: the float32 restatement's own
+    first-pass average is 29 ulps off the exact one, beyond the 4 + 2.5 sqrt(41) = 20 the envelope allowed, and a tuned
+    kernel that sums in another order landed on the other side (2377.14 vs 2375.72; exact 2376.33).  The envelope now
+    moves the average by the summation bound over the taps that can round, 4 + n_sig / 2 ulps (oracle n_significant)."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "k1_sum_bound.npz"))
+    win, ss, cs, ds = z["params"]
+    ref, env = oracle.jbf_kernel(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds), return_ill=True)
+    c = (9, 9)
+    assert env.flags[c] & oracle.Env.COND
+    assert abs(ref[c] - 2375.724) < 1e-2
+    assert env.lo[c] < ref[c] - 1.0 and env.hi[c] > z["observed"][0] + 1.0      # both sides of the exact value, with room
+    # the bound itself: a float32 running sum of n positive terms is off by at most (n - 1) / 2 ulps
+    rng = np.random.default_rng(0)
+    for n in (64, 160, 361):
+        w = rng.choice(np.array([1.0, 0.8148102, 0.3678794, 0.0307], F), n)
+        acc = F(0.0)
+        for v in w:
+            acc = F(acc + v)
+        exact = float(w.astype(np.float64).sum())
+        assert abs(float(acc) - exact) <= 0.5 * n * exact * 2.0 ** -23
+
+
 def test_envelope_keeps_denormal_range_weights(oracle):
     depth, bgr = _denormal_weight_scene()
     ref, env = oracle.jbf_kernel(depth, bgr, 5, 3.0, 7.65, 20.0, return_ill=True)
