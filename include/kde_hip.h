@@ -198,7 +198,8 @@ typedef struct kde_ers kde_ers;
 int kde_ers_create(kde_ers** out, int width, int height);
 int kde_ers_destroy(kde_ers* h);
 /* void EdgeRefining(int* color_label_device, int* depth_label_device, float* depth_device,
- *                   cv::gpu::GpuMat color_image) (EdgeRefinedSuperpixel.cu:208-223) */
+ *                   cv::gpu::GpuMat color_image) (EdgeRefinedSuperpixel.cu:208-223).
+ * Labels are what the segmenters write: -1 (unassigned) or a superpixel index in [0, width * height). */
 int kde_ers_edge_refining(kde_ers* h, const int32_t* color_labels_dev, const int32_t* depth_labels_dev,
                           const float* depth_dev, const uint8_t* bgr_dev, void* stream);
 /* (no reference counterpart) which depthmap_enhancement kernel serves the handle: 0 = built-in choice,
