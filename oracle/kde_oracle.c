@@ -582,8 +582,9 @@ void okde_buf_update(int n, okde_weighted_d* buf, const float* data)
         float d = data[i];
         if (d > 50.0f) {
             if (ref->d != 0.0f) {
-                int diff = f2i_rz(ref->d) - f2i_rz(d);
-                if (diff < 0) diff = -diff;
+                /* abs((int)ref.d - (int)d) as the GPU computes it: two's-complement wrap-around, abs(INT_MIN) = INT_MIN */
+                const unsigned ud = (unsigned)f2i_rz(ref->d) - (unsigned)f2i_rz(d);
+                const int diff = (ud & 0x80000000u) ? (int)(0u - ud) : (int)ud;
                 if ((float)diff < d * 0.01f) {
                     ref->d = ((ref->d * (ref->w + 1.0f)) + (d * ref->w)) / (ref->w * 2.0f + 1.0f);
                     ref->w = ref->w + 1.0f;

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Randomised HIP-vs-oracle parity sweep (the oracle is the checker, as in tests/): random sizes, windows, sigmas,
 hole densities and scene seeds through K1 (every tuned window and the generic kernel), K0, MRF, and the
-RegionGrowingBilateralFilter pipeline (K6-K10; labels exact).  Prints one line per case and a summary; exit code 1
-on any violation.  Usage on the GPU box:  python tools/stress_parity.py --cases 200 --seed 1"""
+RegionGrowingBilateralFilter / SPDepthSuperResolution / DepthAdaptiveSuperpixel pipelines (K6-K10; labels exact); with
+--extended also EdgeRefinedSuperpixel alone on arbitrary label maps and DimensionConvertor / Buffer2D on hostile values
+(bit-exact).  Prints one line per case and a summary; exit code 1 on any violation; --dump DIR keeps the inputs, the
+oracle's envelope and the GPU output of every failing case.  Usage on the GPU box:
+    python tools/stress_parity.py --cases 200 --seed 1 [--extended] [--only KIND] [--dump DIR]"""
 import argparse
 import os
 import sys
@@ -43,7 +46,7 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
     state = {}
     for case in range(a.cases):
         state.clear()
-        kind = ["k1", "k1", "k1", "k0", "mrf", "rgbf", "spdsr", "dasp", "dasp", "ers"][int(rng.integers(0, 10 if a.ers else 9))]
+        kind = ["k1", "k1", "k1", "k0", "mrf", "rgbf", "spdsr", "dasp", "dasp", "ers", "stream"][int(rng.integers(0, 11 if a.ers else 9))]
         if a.only:
             kind = a.only
         w, h = int(rng.integers(1, 200)), int(rng.integers(1, 150))
@@ -124,6 +127,76 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
                     assert np.array_equal(gm[fld], mean[fld]), f"DASP mean.{fld}"
                 assert np.array_equal(host(dsp.getCentersDevice()), pts_as_f32(centers), equal_nan=True), "DASP centres"
                 desc = f"dasp {w}x{h} grid {rows}x{cols} sig {sig} it {it}"
+            elif kind == "stream":
+                # DimensionConvertor / Buffer2D, bit for bit, on hostile values (0, negative, denormal, huge, +-inf, NaN,
+                # the 50 mm validity edge), random intrinsics, random sizes and pointers 0 / 4 / 8 / 12 bytes off alignment
+                from gpu_util import pts_as_f32
+                w, h = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+                nf = int(rng.integers(1, 5))
+
+                def hostile(shape):
+                    d = (rng.random(shape) * 8000.0).astype(np.float32)
+                    special = np.array([0.0, -5.0, 1e-40, 1e30, np.inf, -np.inf, np.nan, 50.0, 50.000004, -1e30, 2147483648.0, 0.5],
+                                       np.float32)
+                    m = rng.random(shape) < rng.uniform(0.0, 0.3)
+                    d[m] = special[rng.integers(0, len(special), int(m.sum()))]
+                    return d
+
+                def off_dev(a, off):
+                    flat = torch.empty(a.size + off, dtype=torch.float32, device="cuda")
+                    v = flat[off:].view(a.shape)
+                    v.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+                    return v
+                depth = hostile((nf, h, w))
+                K = np.array([[rng.uniform(30, 3000), 0, rng.uniform(0, w)], [0, rng.uniform(30, 3000), rng.uniform(0, h)], [0, 0, 1.0]])
+                conv = F.DimensionConvertor()
+                conv.setCameraParameters(K, w, h)
+                o1, o2 = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+                d = off_dev(depth, o1)
+                pts = off_dev(np.zeros((nf, h, w, 3), np.float32), o2)
+                conv.projectiveToReal(d, pts)
+                ref = [O.p2r_depth(depth[i], K) for i in range(nf)]
+                same = lambda g, r: np.array_equal(g, r, equal_nan=True)
+                for i in range(nf):
+                    assert same(host(pts[i]), pts_as_f32(ref[i])), "projectiveToReal(float*)"
+                out = off_dev(np.zeros((nf, h, w, 3), np.float32), o1)
+                conv.realToProjective(pts, out)
+                for i in range(nf):
+                    assert same(host(out[i]), pts_as_f32(O.r2p(ref[i], K))), "realToProjective"
+                back = off_dev(np.zeros((nf, h, w, 3), np.float32), o2)
+                conv.projectiveToReal(out, back)
+                for i in range(nf):
+                    assert same(host(back[i]), pts_as_f32(O.p2r_points(O.r2p(ref[i], K), K))), "projectiveToReal(float3*)"
+                conv.projectiveToRealInterp(d, back)
+                for i in range(nf):
+                    assert same(host(back[i]), pts_as_f32(O.p2r_interp(depth[i], K))), "projectiveToRealInterp"
+                # Buffer2D: inserts and update sequences, single and fused
+                gb, ob = F.Buffer2D(w, h), O.Buffer2D(w, h)
+                seq = hostile((6, h, w))
+                base = (rng.random((h, w)) * 4000.0 + 400.0).astype(np.float32)
+                near = rng.random((6, h, w)) < 0.7                    # most samples close to a common scene: the average path
+                seq[near] = (base[None] * (1.0 + rng.normal(0, 0.004, (6, h, w)))).astype(np.float32)[near]
+                raw = lambda: host(gb.getRawPointer())
+                oraw = lambda: ob.buf.view(np.float32).reshape(h, w, 2)
+                mode = int(rng.integers(0, 3))
+                if mode == 1:
+                    gb.insertData(off_dev(seq[0], o1)); ob.insert_depth(seq[0])
+                elif mode == 2:
+                    xy = np.stack([seq[0], seq[1]], -1)
+                    gb.insertData(off_dev(xy, o2)); ob.insert_float2(xy)
+                assert same(raw(), oraw()), "Buffer2D insertData"
+                k1 = int(rng.integers(0, 4))
+                for i in range(k1):
+                    gb.updateData(off_dev(seq[i], o1)); ob.update(seq[i])
+                assert same(raw(), oraw()), "Buffer2D updateData"
+                if k1 < 6:
+                    gb.updateData(off_dev(seq[k1:], o2))
+                    for i in range(k1, 6):
+                        ob.update(seq[i])
+                assert same(raw(), oraw()), "Buffer2D fused update sequence"
+                og = torch.empty((h, w), dtype=torch.float32, device="cuda")
+                assert same(host(gb.getDepthMap(og)), ob.depth_map()) and same(host(gb.getWeightMap(og)), ob.weight_map())
+                desc = f"stream {w}x{h} frames {nf} offsets {o1}/{o2} insert mode {mode} singles {k1}"
             elif kind == "ers":
                 # EdgeRefinedSuperpixel alone on ARBITRARY label maps (not only what DASP produces): two Voronoi
                 # partitions whose boundaries run within a few pixels of each other -- what edge_refining acts on --
@@ -239,9 +312,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--ers", action="store_true", help="add the stand-alone EdgeRefinedSuperpixel kind (arbitrary label maps); "
-                    "off by default so that the case sequence of a seed stays what earlier logs recorded")
-    ap.add_argument("--only", default="", choices=["", "k1", "k0", "mrf", "rgbf", "spdsr", "dasp", "ers"], help="run one kind only")
+    ap.add_argument("--extended", "--ers", dest="ers", action="store_true",
+                    help="add the kinds 'ers' (stand-alone EdgeRefinedSuperpixel on arbitrary label maps) and 'stream' "
+                    "(DimensionConvertor / Buffer2D on hostile values); off by default so that the case sequence of a seed "
+                    "stays what earlier logs recorded")
+    ap.add_argument("--only", default="", choices=["", "k1", "k0", "mrf", "rgbf", "spdsr", "dasp", "ers", "stream"], help="run one kind only")
     ap.add_argument("--dump", default="", help="directory for the inputs / outputs of failing cases (npz)")
     a = ap.parse_args()
     sys.exit(1 if run(a.cases, a.seed, a.dump, a.ers, a.only) else 0)
