@@ -202,8 +202,10 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
                 # partitions whose boundaries run within a few pixels of each other -- what edge_refining acts on --
                 # with label values anywhere in [-1, w*h), through all four kernel variants
                 w, h = int(rng.integers(8, 300)), int(rng.integers(8, 200))
+                if rng.random() < 0.15:                                  # degenerate frames: thinner than the window
+                    w, h = int(rng.integers(1, 9)), int(rng.integers(1, 9))
                 bgr, depth = scene(w, h)
-                k = int(rng.integers(2, 40))
+                k = int(rng.integers(2, min(40, w * h) + 1)) if w * h >= 2 else 1
                 sy, sx = rng.uniform(0, h, k), rng.uniform(0, w, k)
                 yy, xx = np.mgrid[0:h, 0:w]
 
