@@ -84,7 +84,11 @@ int kde_jbf_create(kde_jbf** out, int width, int height, int max_batch, const kd
 /* JointBilateralFilter::~JointBilateralFilter (JointBilateralFilter.cpp:21-30) */
 int kde_jbf_destroy(kde_jbf* h);
 /* void JointBilateralFilter::Process(float* depth_device, cv::gpu::GpuMat color_image)
- * (JointBilateralFilter.cu:283-290).  bgr_step is GpuMat::step and must equal 3*width. */
+ * (JointBilateralFilter.cu:283-290).  bgr_step is GpuMat::step and must equal 3*width.
+ * Depth is in millimetres; samples that are NaN, -inf or <= 50 are absent taps, as in the reference.  +inf and samples
+ * above 2^64 make every output whose window holds them non-finite garbage in the reference; the tuned kernels keep all
+ * other pixels exact to the usual bar but do not reproduce that garbage class for class (kde_jbf_set_variant(h, 0)
+ * does).  DESIGN.md section 3, "input domain". */
 int kde_jbf_process(kde_jbf* h, const float* depth_dev, const uint8_t* bgr_dev, size_t bgr_step, void* stream);
 /* the same over n <= max_batch independent frames; filtered_dev == NULL writes the object-owned buffer */
 int kde_jbf_process_batch(kde_jbf* h, int n, const float* depth_dev, const uint8_t* bgr_dev,
@@ -199,7 +203,8 @@ int kde_ers_create(kde_ers** out, int width, int height);
 int kde_ers_destroy(kde_ers* h);
 /* void EdgeRefining(int* color_label_device, int* depth_label_device, float* depth_device,
  *                   cv::gpu::GpuMat color_image) (EdgeRefinedSuperpixel.cu:208-223).
- * Labels are what the segmenters write: -1 (unassigned) or a superpixel index in [0, width * height). */
+ * Labels are what the segmenters write: -1 (unassigned) or a superpixel index in [0, width * height).
+ * Depth domain as for kde_jbf_process (+inf / > 2^64 samples: kde_ers_set_variant(h, 3) reproduces the reference). */
 int kde_ers_edge_refining(kde_ers* h, const int32_t* color_labels_dev, const int32_t* depth_labels_dev,
                           const float* depth_dev, const uint8_t* bgr_dev, void* stream);
 /* (no reference counterpart) which depthmap_enhancement kernel serves the handle: 0 = built-in choice,

@@ -149,6 +149,53 @@ def test_k10_every_kernel_variant(torch_cuda, F, oracle, synth, frame, variant):
         F.EdgeRefinedSuperpixel(32, 32).set_variant(9)
 
 
+def test_ers_non_finite_and_huge_depth_samples(torch_cuda, F, oracle, synth, frame):
+    """Input domain of depthmap_enhancement (as tests/test_gpu_jbf.py::test_non_finite_and_huge_depth_samples for K1):
+    +inf / 3e38 mm samples make their 7x7 window non-finite in the reference.  The generic kernels (variant 3) reproduce
+    that class for class; the tuned ones (weights at 2^24 scale) guarantee every pixel whose window holds no such sample,
+    and samples up to 2^64 mm everywhere.  Labels and edge_refining are exact regardless."""
+    bgr, depth = frame(6, 120, 80)
+    h, w = depth.shape
+    K = synth.intrinsics(w, h)
+    pts = oracle.p2r_depth(depth, K)
+    cl = oracle.dasp_segmentation(bgr, pts, 5, 6, K, 200.0, 40.0, 0.0, 1)[0]
+    dl = oracle.dasp_segmentation(bgr, pts, 5, 6, K, 100.0, 20.0, 200.0, 1)[0]
+    spots = {(10, 10): np.inf, (30, 50): np.inf, (31, 52): -np.inf, (50, 20): 3.0e38, (12, 70): np.nan}
+    hostile = depth.copy()
+    for (y, x), v in spots.items():
+        hostile[y, x] = v
+    big = depth.copy()
+    big[40, 40] = 2.0 ** 64
+    classes = lambda a: np.where(np.isnan(a), 2, np.where(np.isinf(a), 3, 0))
+    ers = F.EdgeRefinedSuperpixel(w, h)
+
+    def run(v, d):
+        ers.set_variant(v)
+        ers.EdgeRefining(dev(torch_cuda, cl), dev(torch_cuda, dl), dev(torch_cuda, d), dev(torch_cuda, bgr))
+        return host(ers.getRefinedLabels_Device()).copy(), host(ers.getEdgeStageDepth_Device()).copy(), host(ers.getRefinedDepth_Device()).copy()
+
+    rl, rd9 = oracle.ers_edge_refining(cl, dl, hostile)
+    with oracle.ers_flags((h, w)) as env:
+        ref = oracle.ers_enhance(rd9, bgr, rl)
+    touched = np.zeros((h, w), bool)
+    for y, x in zip(*np.nonzero(rd9 > 1e30)):
+        touched[max(0, y - 3):y + 4, max(0, x - 3):x + 4] = True
+    assert np.isfinite(ref[~touched]).all()
+    for v in (0, 1, 2, 3):
+        gl, g9, g = run(v, hostile)
+        assert np.array_equal(gl, rl) and np.array_equal(g9, rd9, equal_nan=True)
+        if v == 3:
+            assert np.array_equal(classes(g), classes(ref))
+        assert_depth_close(np.where(touched, 0, g), np.where(touched, 0, ref), 1e-4, ill=env, what=f"hostile depth, K10 variant {v}")
+    rlb, rd9b = oracle.ers_edge_refining(cl, dl, big)
+    with oracle.ers_flags((h, w)) as envb:
+        refb = oracle.ers_enhance(rd9b, bgr, rlb)
+    for v in (0, 1, 2, 3):
+        gl, g9, g = run(v, big)
+        assert np.array_equal(gl, rlb) and np.array_equal(g9, rd9b)
+        assert_depth_close(g, refb, 1e-4, ill=envb, what=f"2^64 mm sample, K10 variant {v}")
+
+
 def test_rgbf_pipeline_on_reference_color_fixture(torch_cuda, F, oracle, color_fixture, synth):
     _, depth = synth.make_frame(1, 640, 480)
     K = synth.intrinsics(640, 480)

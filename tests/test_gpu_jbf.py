@@ -216,6 +216,54 @@ def test_weights_of_the_last_denormal_unit_are_kept(torch_cuda, F, oracle):
             assert_depth_close(got, ref, RTOL, ill=env, what=f"last denormal unit, variant {nm} window {win}")
 
 
+def test_non_finite_and_huge_depth_samples(torch_cuda, F, oracle, frame):
+    """What is guaranteed for depth values no sensor produces (input domain).  A tap of +inf or of
+    3e38 mm is "valid" (> 50) in the reference and turns its window into NaN / inf / 1e37.  (a) The reference-shaped
+    kernel reproduces that class for class.  (b) The tuned kernels sum weights at 2^24 scale, so their guarantee ends at
+    2^64 mm: a 2^64 sample still matches everywhere; beyond it the pixels whose window holds such a sample are
+    non-finite garbage in both implementations but not necessarily the same garbage -- every OTHER pixel is held to
+    the usual bar.  -inf and NaN are "not > 50" and simply absent, as in the reference."""
+    bgr, depth = frame(5, 96, 64)
+    h, w = depth.shape
+    hostile = depth.copy()
+    spots = {(10, 10): np.inf, (30, 50): np.inf, (31, 52): -np.inf, (50, 20): 3.0e38, (12, 70): np.nan}
+    for (y, x), v in spots.items():
+        hostile[y, x] = v
+    big = depth.copy()
+    big[40, 40] = 2.0 ** 64
+
+    def classes(a):
+        return np.where(np.isnan(a), 2, np.where(np.isinf(a), 3, 0))
+
+    for win in (5, 11, 19):
+        cfg = (win, 3.0, 7.65, 20.0) if win > 5 else (5, 70.0, 50.0, 20.0)
+        jbf = F.JointBilateralFilter(w, h, params(F, *cfg, pre=0))
+        out = torch_cuda.empty((1, h, w), dtype=torch_cuda.float32, device="cuda")
+
+        def run(v, d):
+            jbf.set_variant(v)
+            jbf.filter_batch(dev(torch_cuda, d[None]), dev(torch_cuda, bgr[None]), out)
+            return host(out)[0].copy()
+
+        ref, env = oracle.jbf_kernel(hostile, bgr, *cfg, return_ill=True)
+        touched = np.zeros((h, w), bool)                        # pixels whose window holds a +inf / 3e38 sample
+        r = win // 2
+        for (y, x), v in spots.items():
+            if v > 1e30:
+                touched[max(0, y - r):y + r + 1, max(0, x - r):x + r + 1] = True
+        assert np.isfinite(ref[~touched]).all() and (~np.isfinite(ref[touched])).sum() > 0
+        g0 = run(0, hostile)                                    # (a) reference-shaped kernel
+        assert np.array_equal(classes(g0), classes(ref))
+        fin = np.isfinite(ref)
+        assert_depth_close(np.where(fin, g0, 0), np.where(fin, ref, 0), RTOL, ill=env, what=f"hostile depth, generic, window {win}")
+        g1 = run(-1, hostile)                                   # (b) tuned kernel: every untouched pixel as usual
+        assert_depth_close(np.where(touched, 0, g1), np.where(touched, 0, ref), RTOL, ill=env, what=f"hostile depth, tuned, window {win}")
+        assert (~np.isfinite(g1[touched & ~fin])).all()        # where the reference is non-finite, so is the tuned kernel
+        refb, envb = oracle.jbf_kernel(big, bgr, *cfg, return_ill=True)
+        assert np.isfinite(refb).all()
+        assert_depth_close(run(-1, big), refb, RTOL, ill=envb, what=f"2^64 mm sample, tuned, window {win}")
+
+
 @pytest.mark.parametrize("win", [11, 19])
 def test_rule_elision_bodies_all_match_the_oracle(torch_cuda, F, oracle, win):
     """K1's tuned kernels (windows >= 9) pick, per tile, a body without the colour and / or depth Q1 rule when the
