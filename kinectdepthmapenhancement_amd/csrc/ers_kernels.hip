@@ -203,7 +203,9 @@ __global__ __launch_bounds__(256) void edge_fused_kernel(int width, int height,
     __shared__ float sD[LH * LP];
 
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * kEdgeTX, y0 = blockIdx.y * kEdgeTY;
+    const unsigned tiles_x = (unsigned)((width + kEdgeTX - 1) / kEdgeTX);
+    const unsigned tile = xcd_band_id(blockIdx.x, gridDim.x);       // 1-D grid of tiles_x * tiles_y workgroups
+    const int x0 = (int)(tile % tiles_x) * kEdgeTX, y0 = (int)(tile / tiles_x) * kEdgeTY;
     {
         // Staging.  Every load is issued before the first one is consumed: addresses are clamped into the image
         // (always valid) and out-of-image elements are zeroed afterwards.  The 64 tile columns go row by row (one
@@ -702,7 +704,9 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
 
     __shared__ uint32_t s_rng[2];                 // bit patterns of the smallest / largest valid depth staged (tile + halo)
 
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const unsigned tiles_x = (unsigned)((a.width + TW - 1) / TW);
+    const unsigned tile = xcd_band_id(blockIdx.x, gridDim.x);       // 1-D grid of tiles_x * tiles_y workgroups
+    const int x0 = (int)(tile % tiles_x) * TW, y0 = (int)(tile / tiles_x) * TH;
     const int tid = threadIdx.x;
     if (tid < 2) s_rng[tid] = tid == 0 ? 0x7f800000u : 0u;
     __syncthreads();
@@ -1038,7 +1042,7 @@ int launch_ers_edge_refining(int width, int height, int window, const int32_t* c
     // The fused kernel's halo (window/2 + 3) and register window are laid out for the reference's window of 7
     // (EdgeRefinedSuperpixel.cpp:4); any other window runs the two-launch form, whose rule takes any reach.
     if (!two_launches && window / 2 == 3) {
-        const dim3 grid(ceil_div(width, kEdgeTX), ceil_div(height, kEdgeTY));
+        const dim3 grid(ceil_div(width, kEdgeTX) * ceil_div(height, kEdgeTY));
         hipLaunchKernelGGL(edge_fused_kernel<3>, grid, dim3(256), 0, s, width, height, color_labels, l0, d0, l2, d2);
         KDE_HIP_TRY(hipGetLastError());
         return KDE_OK;
@@ -1114,7 +1118,7 @@ int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bg
         }
         // first rank from which every threshold is 1 (the sigmas only shrink with the rank: once 1, always 1)
         for (int k = 49; k >= 1 && d.tthr[k] >= -1.0f; k--) d.kfree = k;
-        hipLaunchKernelGGL(enhance7_pk_kernel, dim3(ceil_div(width, kE7BX * 2), ceil_div(height, kE7BY)),
+        hipLaunchKernelGGL(enhance7_pk_kernel, dim3(ceil_div(width, kE7BX * 2) * ceil_div(height, kE7BY)),
                            dim3(kE7BX * kE7BY), 0, s, d);
         KDE_HIP_TRY(hipGetLastError());
         return KDE_OK;

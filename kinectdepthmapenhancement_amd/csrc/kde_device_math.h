@@ -30,4 +30,14 @@ __device__ __forceinline__ float exp_denormal(float x)
     return shifted ? r * 0x1.969d48p-93f : r;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Mapping workgroup `lin` of `nblk` to the
+// tile xcd_band_id(lin, nblk) gives XCD k the k-th contiguous eighth of the (raster-ordered) tile list, so the halo
+// rows two neighbouring tiles share are fetched into one L2 instead of two.  Bijective for any nblk.
+__device__ __forceinline__ unsigned xcd_band_id(unsigned lin, unsigned nblk)
+{
+    const unsigned per = nblk / 8, rem = nblk % 8;
+    const unsigned xcd = lin % 8, slot = lin / 8;
+    return xcd * per + (xcd < rem ? xcd : rem) + slot;
+}
+
 }  // namespace kde
