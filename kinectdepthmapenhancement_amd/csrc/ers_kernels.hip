@@ -1039,8 +1039,9 @@ int launch_ers_edge_refining(int width, int height, int window, const int32_t* c
                              const float* d0, int32_t* scratch_l, float* scratch_d, int32_t* l2, float* d2, bool two_launches,
                              hipStream_t s)
 {
-    // The fused kernel's halo (window/2 + 3) and register window are laid out for the reference's window of 7
-    // (EdgeRefinedSuperpixel.cpp:4); any other window runs the two-launch form, whose rule takes any reach.
+    // The fused kernel's halos (colour labels +-(2 + window/2), depth labels / depth -2..+3) and register window are
+    // laid out for the reference's window of 7 (EdgeRefinedSuperpixel.cpp:4); any other window runs the two-launch
+    // form, whose rule takes any reach.
     if (!two_launches && window / 2 == 3) {
         const dim3 grid(ceil_div(width, kEdgeTX) * ceil_div(height, kEdgeTY));
         hipLaunchKernelGGL(edge_fused_kernel<3>, grid, dim3(256), 0, s, width, height, color_labels, l0, d0, l2, d2);
