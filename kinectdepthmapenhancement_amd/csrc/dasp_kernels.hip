@@ -12,6 +12,7 @@
 //   All grids are ceil-div and bounds-guarded (D4); out-of-buffer taps of K6 read colour 0 (D1).
 #include "kde_internal.h"
 #include "kde_device_math.h"
+#include <type_traits>
 
 namespace kde {
 namespace {
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void sample_clusters_kernel(DaspGeom g, const 
 // ---- K7 calculateLD<16> (.cu:167-313) -------------------------------------------------------------
 struct ClusterRec {   // LDS copy of one cluster: 32 B
     float r, g, b;
-    int x, y;
+    float x, y;           // pixel coordinates as floats (exact below 2^24): offsets to a pixel are one v_sub_f32 each
     float cz;
     int pad0, pad1;
 };
@@ -151,8 +152,8 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
                 r.r = (float)m.r;
                 r.g = (float)m.g;
                 r.b = (float)m.b;
-                r.x = m.x;
-                r.y = m.y;
+                r.x = (float)m.x;
+                r.y = (float)m.y;
                 r.cz = sets.s[n].centers[i].z;
                 r.pad0 = r.pad1 = 0;
                 recs[n * nclusters + i] = r;
@@ -165,22 +166,22 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
     const size_t p = (size_t)y * g.width + x;
     const float c0 = (float)bgr[p * 3], c1 = (float)bgr[p * 3 + 1], c2 = (float)bgr[p * 3 + 2];
     const float z = pts[p].z;
+    const float xf = (float)x, yf = (float)y;
 
     // the three distances of candidate t against cluster table n (.cu:196-217)
     auto candidate = [&](int n, int id, float& color_distance, float& spatial_distance, float& depth_distance) {
-        float mr, mg, mb, cz;
-        int mx, my;
+        float mr, mg, mb, cz, mx, my;
         if (USE_LDS) {
             const ClusterRec r = recs[n * nclusters + id];
             mr = r.r; mg = r.g; mb = r.b; mx = r.x; my = r.y; cz = r.cz;
         } else {
             const kde_superpixel m = sets.s[n].mean[id];
-            mr = (float)m.r; mg = (float)m.g; mb = (float)m.b; mx = m.x; my = m.y;
+            mr = (float)m.r; mg = (float)m.g; mb = (float)m.b; mx = (float)m.x; my = (float)m.y;
             cz = sets.s[n].centers[id].z;
         }
         const float e0 = c0 - mr, e1 = c1 - mg, e2 = c2 - mb;
         color_distance = e0 * e0 + e1 * e1 + e2 * e2;
-        const float px = (float)(x - mx), py = (float)(y - my);
+        const float px = xf - mx, py = yf - my;       // = (float)(x - mx): integers below 2^24
         spatial_distance = sqrt_int24(px * px + py * py) * win2;
         depth_distance = 0.0f;
         if (z > 50.0f && cz > 50.0f) depth_distance = fabsf(z - cz);
@@ -192,11 +193,15 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
     // a 1e-5 margin; colour and depth terms are >= 0) can neither win nor tie.  The skip is taken when no lane of
     // the wavefront needs the candidate; typically 5 of 16 are evaluated.  Segmenters lo..hi share table `tab` and
     // the previous assignment `cur` (all of them in the FIRST step, one at a time later).
-    auto assign = [&](int tab, int lo, int hi, const kde_label_distance cur) {
+    // inner = every lane's 4 x 4 candidate block lies inside the cluster grid (wavefront-uniform, std::true_type /
+    // std::false_type): no candidate can be "outside the grid", so its tests and selects are not even compiled in
+    auto assign_impl = [&](auto inner, int tab, int lo, int hi, const kde_label_distance cur) {
+        constexpr bool INNER = decltype(inner)::value;
         const int ccx = cur.l % g.cols, ccy = cur.l / g.cols;
         auto grid_id = [&](int t) {
             const int rx = ccx - 2 + (t & 3), ry = ccy - 2 + (t >> 2);
-            return (rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows) ? ry * g.cols + rx : -1;
+            if constexpr (INNER) return ry * g.cols + rx;
+            else return (rx >= 0 && rx < g.cols && ry >= 0 && ry < g.rows) ? ry * g.cols + rx : -1;
         };
         float best[NS], thr[NS], own_d[NS];
         int bl[NS];
@@ -216,36 +221,37 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
                 bl[n] = cur.l;
             }
         }
+        float thr_any = -INFINITY;                    // the largest of the thresholds (NaN-free: thr is q*q or +inf)
+#pragma unroll
+        for (int n = 0; n < NS; n++)
+            if (n >= lo && n <= hi) thr_any = fmaxf(thr_any, thr[n]);
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int t = ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);   // bit-reversed scan
             const int id = grid_id(t);
-            if (t == 10 || id < 0) {
+            if (t == 10 || (!INNER && id < 0)) {
 #pragma unroll
                 for (int n = 0; n < NS; n++) {
                     if (n < lo || n > hi) continue;
-                    const float d = id < 0 ? cur.d : own_d[n];                    // .cu:221-224 outside the grid
-                    const int l = id < 0 ? cur.l : id;
+                    const float d = (!INNER && id < 0) ? cur.d : own_d[n];        // .cu:221-224 outside the grid
+                    const int l = (!INNER && id < 0) ? cur.l : id;
                     const bool take = d < best[n];
                     best[n] = take ? d : best[n];
                     bl[n] = take ? l : bl[n];
                 }
                 continue;
             }
-            int mx, my;
+            float mx, my;
             if (USE_LDS) {
                 mx = recs[tab * nclusters + id].x;
                 my = recs[tab * nclusters + id].y;
             } else {
-                mx = sets.s[tab].mean[id].x;
-                my = sets.s[tab].mean[id].y;
+                mx = (float)sets.s[tab].mean[id].x;
+                my = (float)sets.s[tab].mean[id].y;
             }
-            const float px = (float)(x - mx), py = (float)(y - my);
+            const float px = xf - mx, py = yf - my;
             const float n2 = px * px + py * py;
-            bool need = false;
-#pragma unroll
-            for (int n = 0; n < NS; n++)
-                if (n >= lo && n <= hi) need |= !(n2 > thr[n]);
+            const bool need = !(n2 > thr_any);       // some segmenter of this pass may still need the candidate
             if (__builtin_amdgcn_ballot_w64(need) == 0) continue;              // nobody in the wavefront needs it
             float cdv, sdv, ddv;
             candidate(tab, id, cdv, sdv, ddv);
@@ -273,6 +279,12 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
             cs.ld[p] = o;
             cs.labels[p] = o.l;
         }
+    };
+    auto assign = [&](int tab, int lo, int hi, const kde_label_distance cur) {
+        const int ccx = cur.l % g.cols, ccy = cur.l / g.cols;
+        const bool in = cur.l >= 0 && ccx >= 2 && ccx + 1 < g.cols && ccy >= 2 && ccy + 1 < g.rows;
+        if (__builtin_amdgcn_ballot_w64(!in) == 0) assign_impl(std::true_type{}, tab, lo, hi, cur);
+        else assign_impl(std::false_type{}, tab, lo, hi, cur);
     };
 
     if (FIRST) {
