@@ -135,9 +135,14 @@ struct CalcSets {
 // kernel and read back by the next -- and all NS segmenters still share the sampled clusters, so the colour /
 // spatial / depth distances of the 16 candidates are computed ONCE and only the weighted sum and the argmin run
 // per segmenter (set 0's cluster table serves all).
+struct CalcDivs {          // divisions of the assignment step by multiplication (kde_device_math.h)
+    FastDiv24 wx, wy, cols;
+};
+
 template <int NS, bool USE_LDS, bool FIRST>
 __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
-                                                     const kde_float3* __restrict__ pts, CalcSets<NS> sets, float win2)
+                                                     const kde_float3* __restrict__ pts, CalcSets<NS> sets, float win2,
+                                                     CalcDivs dv)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ClusterRec* recs = reinterpret_cast<ClusterRec*>(smem);
@@ -195,9 +200,8 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
     // the previous assignment `cur` (all of them in the FIRST step, one at a time later).
     // inner = every lane's 4 x 4 candidate block lies inside the cluster grid (wavefront-uniform, std::true_type /
     // std::false_type): no candidate can be "outside the grid", so its tests and selects are not even compiled in
-    auto assign_impl = [&](auto inner, int tab, int lo, int hi, const kde_label_distance cur) {
+    auto assign_impl = [&](auto inner, int tab, int lo, int hi, const kde_label_distance cur, int ccx, int ccy) {
         constexpr bool INNER = decltype(inner)::value;
-        const int ccx = cur.l % g.cols, ccy = cur.l / g.cols;
         auto grid_id = [&](int t) {
             const int rx = ccx - 2 + (t & 3), ry = ccy - 2 + (t >> 2);
             if constexpr (INNER) return ry * g.cols + rx;
@@ -280,22 +284,37 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
             cs.labels[p] = o.l;
         }
     };
-    auto assign = [&](int tab, int lo, int hi, const kde_label_distance cur) {
-        const int ccx = cur.l % g.cols, ccy = cur.l / g.cols;
+    // (ccx, ccy) = the grid cell of the previous assignment: cur.l % cols, cur.l / cols
+    auto assign = [&](int tab, int lo, int hi, const kde_label_distance cur, int ccx, int ccy) {
         const bool in = cur.l >= 0 && ccx >= 2 && ccx + 1 < g.cols && ccy >= 2 && ccy + 1 < g.rows;
-        if (__builtin_amdgcn_ballot_w64(!in) == 0) assign_impl(std::true_type{}, tab, lo, hi, cur);
-        else assign_impl(std::false_type{}, tab, lo, hi, cur);
+        if (__builtin_amdgcn_ballot_w64(!in) == 0) assign_impl(std::true_type{}, tab, lo, hi, cur, ccx, ccy);
+        else assign_impl(std::false_type{}, tab, lo, hi, cur, ccx, ccy);
     };
 
     if (FIRST) {
         kde_label_distance cur;                                   // init_LD (.cu:3-14)
-        cur.l = (y / g.wy) * g.cols + (x / g.wx);
+        const int cx = (int)fastdiv24((uint32_t)x, dv.wx), cy = (int)fastdiv24((uint32_t)y, dv.wy);
+        cur.l = cy * g.cols + cx;
         cur.d = 999999.9f;
-        assign(0, 0, NS - 1, cur);
+        // (x / wx may reach cols when the width is not a multiple of the cell: cur.l % cols, cur.l / cols then wrap
+        // into the next row, as the reference's arithmetic does)
+        const bool wrap = cx >= g.cols;
+        assign(0, 0, NS - 1, cur, wrap ? cur.l % g.cols : cx, wrap ? cur.l / g.cols : cy);
         return;
     }
 #pragma unroll
-    for (int n = 0; n < NS; n++) assign(n, n, n, sets.s[n].ld[p]);
+    for (int n = 0; n < NS; n++) {
+        const kde_label_distance cur = sets.s[n].ld[p];
+        int ccx, ccy;
+        if (cur.l >= 0) {
+            ccy = (int)fastdiv24((uint32_t)cur.l, dv.cols);
+            ccx = cur.l - ccy * g.cols;
+        } else {                                                  // -1 (unassigned): C's truncating % and /
+            ccx = cur.l % g.cols;
+            ccy = cur.l / g.cols;
+        }
+        assign(n, n, n, cur, ccx, ccy);
+    }
 }
 
 // ---- K8 analyzeClusters<256> (.cu:315-568) ---------------------------------------------------------
@@ -507,12 +526,16 @@ static int launch_calc_sets(const DaspGeom& g, const uint8_t* bgr, const kde_flo
     const bool lds = tables * nclusters <= kMaxLdsClusters;
     const size_t bytes = lds ? (size_t)tables * nclusters * sizeof(ClusterRec) : 0;
     dim3 grid(ceil_div(g.width, 64), ceil_div(g.height, 4));
+    CalcDivs dv;
+    dv.wx = make_fastdiv24((uint32_t)g.wx, (uint64_t)g.width);
+    dv.wy = make_fastdiv24((uint32_t)g.wy, (uint64_t)g.height);
+    dv.cols = make_fastdiv24((uint32_t)g.cols, (uint64_t)g.width * g.height);      // labels are < rows * cols <= pixels
     if (first) {
-        if (lds) hipLaunchKernelGGL((calc_ld_kernel<NS, true, true>), grid, dim3(256), bytes, s, g, bgr, pts, sets, win2);
-        else hipLaunchKernelGGL((calc_ld_kernel<NS, false, true>), grid, dim3(256), 0, s, g, bgr, pts, sets, win2);
+        if (lds) hipLaunchKernelGGL((calc_ld_kernel<NS, true, true>), grid, dim3(256), bytes, s, g, bgr, pts, sets, win2, dv);
+        else hipLaunchKernelGGL((calc_ld_kernel<NS, false, true>), grid, dim3(256), 0, s, g, bgr, pts, sets, win2, dv);
     } else {
-        if (lds) hipLaunchKernelGGL((calc_ld_kernel<NS, true, false>), grid, dim3(256), bytes, s, g, bgr, pts, sets, win2);
-        else hipLaunchKernelGGL((calc_ld_kernel<NS, false, false>), grid, dim3(256), 0, s, g, bgr, pts, sets, win2);
+        if (lds) hipLaunchKernelGGL((calc_ld_kernel<NS, true, false>), grid, dim3(256), bytes, s, g, bgr, pts, sets, win2, dv);
+        else hipLaunchKernelGGL((calc_ld_kernel<NS, false, false>), grid, dim3(256), 0, s, g, bgr, pts, sets, win2, dv);
     }
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;

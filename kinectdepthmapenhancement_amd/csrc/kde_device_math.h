@@ -30,6 +30,29 @@ __device__ __forceinline__ float exp_denormal(float x)
     return shifted ? r * 0x1.969d48p-93f : r;
 }
 
+// x / d for 0 <= x < 2^24 by a multiplication: with l = ceil(log2 d), m = floor(2^(24+l) / d) + 1 and sh = 24 + l,
+// floor(x * m / 2^sh) == floor(x / d) (m * d = 2^sh + e with 0 < e <= 2^l, so the product overshoots x / d by less than
+// 1 / d).  Two instructions (v_mad_u64_u32, v_lshrrev_b64) instead of the ~20 of a 32-bit division.  ok == 0 (operands
+// beyond the proven range) falls back to the division.
+struct FastDiv24 {
+    uint32_t m, sh, d, ok;
+};
+inline FastDiv24 make_fastdiv24(uint32_t d, uint64_t max_dividend)
+{
+    FastDiv24 f{0u, 0u, d, 0u};
+    if (d == 0 || d >= (1u << 24) || max_dividend >= (1ull << 24)) return f;
+    uint32_t l = 0;
+    while ((1u << l) < d) l++;
+    f.sh = 24 + l;
+    f.m = (uint32_t)((1ull << f.sh) / d + 1);      // < 2^(25+l) / d + 1 <= 2^25 + 1: fits
+    f.ok = 1;
+    return f;
+}
+__device__ __forceinline__ uint32_t fastdiv24(uint32_t x, const FastDiv24& f)
+{
+    return f.ok ? (uint32_t)(((uint64_t)x * f.m) >> f.sh) : x / f.d;
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Mapping workgroup `lin` of `nblk` to the
 // tile xcd_band_id(lin, nblk) gives XCD k the k-th contiguous eighth of the (raster-ordered) tile list, so the halo
 // rows two neighbouring tiles share are fetched into one L2 instead of two.  Bijective for any nblk.
