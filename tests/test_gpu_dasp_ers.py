@@ -149,6 +149,33 @@ def test_k10_every_kernel_variant(torch_cuda, F, oracle, synth, frame, variant):
         F.EdgeRefinedSuperpixel(32, 32).set_variant(9)
 
 
+def test_k10_depth_rule_elision_both_bodies(torch_cuda, F, oracle):
+    """depthmap_enhancement's colour-free rows drop the depth-factor underflow rule when the tile's staged depth range
+    proves it cannot trip (< 1009 mm at DepthSigma 70).  Left half: a gentle slope (rule elided).  Right half: stripes
+    1.7 m apart, so taps on the other side of a stripe edge DO underflow and are skipped (Q1) -- the full body.  Both
+    against the oracle, every kernel variant."""
+    h, w = 96, 256
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:h, 0:w]
+    depth = (1500.0 + 0.3 * xx + 0.2 * yy + rng.normal(0, 1.5, (h, w))).astype(np.float32)
+    stripes = (xx >= w // 2) & (((xx // 5) % 2) == 1)
+    depth[stripes] += 1700.0
+    depth[rng.random((h, w)) < 0.02] = 0
+    bgr = np.clip(np.full((h, w, 3), 100, np.int32) + rng.integers(-20, 21, (h, w, 3)), 0, 255).astype(np.uint8)
+    lab = ((yy // 24) * 8 + xx // 32).astype(np.int32)
+    rl, rd9 = oracle.ers_edge_refining(lab, lab, depth)
+    with oracle.ers_flags((h, w)) as env:
+        ref = oracle.ers_enhance(rd9, bgr, rl)
+    # the two halves really differ in their rule use: a pixel next to a stripe edge keeps its own side's depth
+    assert np.isfinite(ref).all()
+    ers = F.EdgeRefinedSuperpixel(w, h)
+    for v in (0, 1, 2, 3):
+        ers.set_variant(v)
+        ers.EdgeRefining(dev(torch_cuda, lab), dev(torch_cuda, lab), dev(torch_cuda, depth), dev(torch_cuda, bgr))
+        assert np.array_equal(host(ers.getEdgeStageDepth_Device()), rd9)
+        assert_depth_close(host(ers.getRefinedDepth_Device()), ref, 1e-4, ill=env, what=f"K10 depth-rule elision, variant {v}")
+
+
 def test_ers_non_finite_and_huge_depth_samples(torch_cuda, F, oracle, synth, frame):
     """Input domain of depthmap_enhancement (as tests/test_gpu_jbf.py::test_non_finite_and_huge_depth_samples for K1):
     +inf / 3e38 mm samples make their 7x7 window non-finite in the reference.  The generic kernels (variant 3) reproduce
