@@ -25,6 +25,7 @@
 // Depth + guide + |b|^2 tiles (with halo) are staged once per workgroup in LDS; the workgroup->tile map
 // keeps each XCD on a contiguous band of tiles so halos are shared in that XCD's L2.
 #include "kde_internal.h"
+#include "kde_device_math.h"
 
 #include <type_traits>
 
@@ -43,6 +44,7 @@ struct FastArgs {
     float* out;
     int width, height, n;
     int tiles_x, tiles_y;
+    FastDiv24 div_tiles, div_tx;   // workgroup -> (frame, tile row, tile column) by multiplication (kde_device_math.h)
     float kc;        // log2(e) / (2 sigma_c^2)
     float sd;        // sqrt(log2(e) / (2 sigma_d^2))
     float t_skip;    // depth factor skipped when |d_q - avg| * sd >= t_skip
@@ -81,9 +83,9 @@ __global__ __launch_bounds__(BX* BY) void jbf_fast_kernel(const FastArgs a)
     const unsigned xcd = lin % 8, slot = lin / 8;
     const unsigned id = xcd * per + (xcd < rem ? xcd : rem) + slot;   // bijective for any nblk
     const unsigned tiles = (unsigned)a.tiles_x * a.tiles_y;
-    const unsigned frame_i = id / tiles;
+    const unsigned frame_i = fastdiv24(id, a.div_tiles);
     const unsigned tile = id - frame_i * tiles;
-    const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+    const int tyi = (int)fastdiv24(tile, a.div_tx), txi = tile - tyi * a.tiles_x;
     const int x0 = txi * TW, y0 = tyi * TH;
 
     const size_t frame = (size_t)frame_i * a.width * a.height;
@@ -296,9 +298,9 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     const unsigned xcd = lin % 8, slot = lin / 8;
     const unsigned id = xcd * per + (xcd < rem ? xcd : rem) + slot;
     const unsigned tiles = (unsigned)a.tiles_x * a.tiles_y;
-    const unsigned frame_i = id / tiles;
+    const unsigned frame_i = fastdiv24(id, a.div_tiles);
     const unsigned tile = id - frame_i * tiles;
-    const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+    const int tyi = (int)fastdiv24(tile, a.div_tx), txi = tile - tyi * a.tiles_x;
     const int x0 = txi * TW - S1, y0 = tyi * TH;
     const int o = x0 - RA;
 
@@ -609,6 +611,8 @@ int launch_pk_variant(const JbfLaunch& l, const FastArgs& fa, bool cskip, hipStr
     a.tiles_x = ceil_div(l.width, BX * NP * 2);
     a.tiles_y = ceil_div(l.height, BY);
     const long long blocks = (long long)a.tiles_x * a.tiles_y * l.n;
+    a.div_tiles = make_fastdiv24((uint32_t)(a.tiles_x * a.tiles_y), (uint64_t)blocks);
+    a.div_tx = make_fastdiv24((uint32_t)a.tiles_x, (uint64_t)a.tiles_x * a.tiles_y);
     if (blocks > 0x7fffffffLL) return fail(KDE_ERR_INVALID, "jbf: batch too large for one launch");
     if (cskip)
         hipLaunchKernelGGL((jbf_pk_kernel<WIN, NP, BX, BY, CACHE, true, VL>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
@@ -625,6 +629,8 @@ int launch_variant(const JbfLaunch& l, const FastArgs& fa, bool cskip, hipStream
     a.tiles_x = ceil_div(l.width, BX * PX);
     a.tiles_y = ceil_div(l.height, BY);
     const long long blocks = (long long)a.tiles_x * a.tiles_y * l.n;
+    a.div_tiles = make_fastdiv24((uint32_t)(a.tiles_x * a.tiles_y), (uint64_t)blocks);
+    a.div_tx = make_fastdiv24((uint32_t)a.tiles_x, (uint64_t)a.tiles_x * a.tiles_y);
     if (blocks > 0x7fffffffLL) return fail(KDE_ERR_INVALID, "jbf: batch too large for one launch");
     if (cskip)
         hipLaunchKernelGGL((jbf_fast_kernel<WIN, PX, BX, BY, CACHE, true>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
