@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--color-sigma", type=float, default=7.65, help="sigma_r=0.03 of the 0..255 range")
     ap.add_argument("--depth-sigma", type=float, default=20.0)
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--wakeup-ms", type=float, default=150.0,
+                    help="untimed load before the W warm-up steps so that the GPU has left its idle clock level (0 = none)")
     ap.add_argument("--distinct-frames", type=int, default=8, help="distinct synthetic frames, tiled to the batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip the 1080p / reference-constant side measurements")
@@ -134,8 +136,8 @@ def make_inputs(synth, torch, first_seed, n, w, h, distinct):
     return torch.from_numpy(bgr).cuda(), torch.from_numpy(depth).cuda()
 
 
-def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier):
-    """W untimed + exactly K timed steps; returns (wall seconds, K0 ms list, K1 ms list)."""
+def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier, wakeup_ms=0.0):
+    """device wake-up, W untimed + exactly K timed steps; returns (wall seconds, K0 ms list, K1 ms list, wake-up steps)."""
     def step(evs=None):
         if evs:
             evs[0].record()
@@ -147,6 +149,16 @@ def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier):
             evs[2].record()
 
     barrier()                                       # also brings the RCCL communicator up before anything is timed
+    # Device wake-up, before the W warm-up steps and outside every timed region: an idle MI355X sits at its lowest
+    # clock level and needs ~100 ms of load to reach the clock it then holds; with W = 5 (6.5 ms) the K timed steps
+    # would otherwise measure that ramp (first step 1.27 ms, last 1.11 ms) instead of the kernel.
+    woke = 0
+    t_w = time.perf_counter()
+    while wakeup_ms > 0 and (time.perf_counter() - t_w) * 1e3 < wakeup_ms:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        woke += 10
     for _ in range(warmup):
         step()
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
@@ -160,7 +172,7 @@ def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier):
     barrier()                                       # by the caller (the collective's own latency is not part of a step)
     k0 = [e[0].elapsed_time(e[1]) for e in evs]
     k1 = [e[1].elapsed_time(e[2]) for e in evs]
-    return dt, k0, k1
+    return dt, k0, k1, woke
 
 
 def usable_cores():
@@ -247,7 +259,7 @@ def main():
     if args.variant >= 0:
         jbf.set_variant(args.variant)
 
-    dt, k0_ms, k1_ms = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier)
+    dt, k0_ms, k1_ms, woke = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, args.wakeup_ms)
     dt = sharding.allreduce_max(dt)
     checksum = sharding.allreduce_sum([float(out.double().sum().item()), float(count)])
 
@@ -259,11 +271,12 @@ def main():
                 "kernel": "K1 joint_bilateral_filtering"}
         roof.update(k1_roofline(px_per_launch, k1_avg_ms, entry, src))
         roof["k0_avg_launch_ms"] = float(np.mean(k0_ms))
+        roof["launch_ms_first_min_max"] = [float(k1_ms[0]), float(np.min(k1_ms)), float(np.max(k1_ms))]   # clock ramp shows here
         res = {
             "metric": METRIC,
             "value": total_frames * W * H * args.steps / dt / 1e6,
             "unit": "Mpixels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "wakeup_steps_before_warmup": woke,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -304,7 +317,7 @@ def side_measurements(torch, filters, synth, args):
         if args.variant >= 0:
             jbf.set_variant(args.variant)
         steps = max(3, min(args.steps, 10))
-        dt, k0, k1 = time_steps(torch, jbf, depth, color, smooth, res, steps, 2, lambda: None)
+        dt, k0, k1, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 2, lambda: None)
         px = n * w * h
         k1m = float(np.mean(k1))
         entry, src = pmc_lookup(args.pmc_json, window)

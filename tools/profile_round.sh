@@ -34,7 +34,7 @@ pmc_passes() {   # <subdir> <program> <args...>: four passes of the same command
 for STEP in $STEPS; do
 case $STEP in
 pmc_bench)
-  SHORT="bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-verify"
+  SHORT="bench.py --steps 3 --warmup 1 --wakeup-ms 0 --cpu-seconds 0 --no-verify"
   pmc_passes pmc_bench python3 $SHORT
   python3 tools/pmc_report.py --dir "$OUT/pmc_bench" --out "$OUT/pmc_bench.json" --command "python3 $SHORT" \
       --algo tools/algo_bytes_bench.json 2> "$OUT/pmc_bench.summary"
