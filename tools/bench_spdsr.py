@@ -16,8 +16,11 @@ def main():
     ap.add_argument("--rows", type=int, default=15)
     ap.add_argument("--cols", type=int, default=20)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--wakeup-ms", type=float, default=150.0, help="untimed load before anything is measured (tools/wake.py)")
     a = ap.parse_args()
     import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from wake import wake
     from kinectdepthmapenhancement_amd import filters as F, synth
     W, H = a.width, a.height
     bgr, depth = synth.make_frame(77, W, H)
@@ -28,6 +31,7 @@ def main():
     conv.projectiveToReal(d, pts)
     sr = F.SPDepthSuperResolution(W, H)
     sr.SetParametor(a.rows, a.cols, K)
+    wake(torch, a.wakeup_ms)
     sr.Process(d, pts, color)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

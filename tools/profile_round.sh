@@ -42,17 +42,17 @@ pmc_bench)
   cat "$OUT/pmc_bench.summary"
   ;;
 pmc_chain)
-  pmc_passes pmc_chain python3 tools/bench_chain.py --iters 5
-  python3 tools/pmc_report.py --dir "$OUT/pmc_chain" --out "$OUT/pmc_chain.json" --command "python3 tools/bench_chain.py --iters 5" \
+  pmc_passes pmc_chain python3 tools/bench_chain.py --iters 5 --wakeup-ms 0
+  python3 tools/pmc_report.py --dir "$OUT/pmc_chain" --out "$OUT/pmc_chain.json" --command "python3 tools/bench_chain.py --iters 5 --wakeup-ms 0" \
       --algo tools/algo_bytes_chain.json 2> "$OUT/pmc_chain.summary"
-  pmc_passes pmc_k0 python3 tools/bench_k0.py
+  pmc_passes pmc_k0 python3 tools/bench_k0.py --wakeup-ms 0
   echo '{"presmooth_kernel": 117964800}' > "$OUT/algo_k0.json"      # 6 B/pixel x 64 x 640x480
-  python3 tools/pmc_report.py --dir "$OUT/pmc_k0" --out "$OUT/pmc_k0.json" --command "python3 tools/bench_k0.py" \
+  python3 tools/pmc_report.py --dir "$OUT/pmc_k0" --out "$OUT/pmc_k0.json" --command "python3 tools/bench_k0.py --wakeup-ms 0" \
       --algo "$OUT/algo_k0.json" 2> "$OUT/pmc_k0.summary"
-  pmc_passes pmc_mrf python3 tools/bench_mrf.py
-  python3 tools/pmc_report.py --dir "$OUT/pmc_mrf" --out "$OUT/pmc_mrf.json" --command "python3 tools/bench_mrf.py" 2> "$OUT/pmc_mrf.summary"
-  pmc_passes pmc_spdsr python3 tools/bench_spdsr.py
-  python3 tools/pmc_report.py --dir "$OUT/pmc_spdsr" --out "$OUT/pmc_spdsr.json" --command "python3 tools/bench_spdsr.py" 2> "$OUT/pmc_spdsr.summary"
+  pmc_passes pmc_mrf python3 tools/bench_mrf.py --wakeup-ms 0
+  python3 tools/pmc_report.py --dir "$OUT/pmc_mrf" --out "$OUT/pmc_mrf.json" --command "python3 tools/bench_mrf.py --wakeup-ms 0" 2> "$OUT/pmc_mrf.summary"
+  pmc_passes pmc_spdsr python3 tools/bench_spdsr.py --wakeup-ms 0
+  python3 tools/pmc_report.py --dir "$OUT/pmc_spdsr" --out "$OUT/pmc_spdsr.json" --command "python3 tools/bench_spdsr.py --wakeup-ms 0" 2> "$OUT/pmc_spdsr.summary"
   cat "$OUT/pmc_chain.summary" "$OUT/pmc_k0.summary" "$OUT/pmc_mrf.summary" "$OUT/pmc_spdsr.summary"
   # one table for the judge: chain + K0 + MRF + SPDSR entries, each tagged with the command it was profiled under
   python3 - "$OUT" <<'PY'

@@ -23,8 +23,11 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--with-generic", action="store_true")
+    ap.add_argument("--wakeup-ms", type=float, default=150.0, help="untimed load before anything is measured (tools/wake.py)")
     a = ap.parse_args()
     import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from wake import wake
     from kinectdepthmapenhancement_amd import filters, synth
     bgr, depth = synth.make_batch(500, min(a.frames, 2), a.width, a.height)
     reps = -(-a.frames // bgr.shape[0])
@@ -38,6 +41,7 @@ def main():
     names = filters.JointBilateralFilter.variants()
     todo = [v for v, nm in enumerate(names) if v == 0 and a.with_generic or v != 0 and int(nm.split("-")[0][1:]) == a.window]
     times = {v: [] for v in todo}
+    wake(torch, a.wakeup_ms)
     for rnd in range(a.rounds + 1):            # interleaved rounds in one process; round 0 is warm-up
         for v in todo:
             jbf.set_variant(v)
