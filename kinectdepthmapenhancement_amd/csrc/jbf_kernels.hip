@@ -195,11 +195,15 @@ __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
         const int tile = t - frame_i * tiles_per_frame;
         const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
         const size_t frame = (size_t)frame_i * a.width * a.height;
+        // a tile whose halo stays inside the image needs no border reflection (workgroup-uniform)
+        const bool inner = txi * kPreTW - R >= 0 && txi * kPreTW + kPreTW + R <= a.width && tyi * kPreTH - R >= 0 &&
+                           tyi * kPreTH + kPreTH + R <= a.height;
 #pragma unroll
         for (int k = 0; k < NSLOT; k++) {
             if (tid + k * NT < LW * LH) {
-                const int gx = reflect101(txi * kPreTW + slot_x[k] - R, a.width);
-                const int gy = reflect101(tyi * kPreTH + slot_y[k] - R, a.height);
+                const int ux = txi * kPreTW + slot_x[k] - R, uy = tyi * kPreTH + slot_y[k] - R;
+                const int gx = inner ? ux : reflect101(ux, a.width);
+                const int gy = inner ? uy : reflect101(uy, a.height);
                 const size_t pix = frame + (size_t)gy * a.width + gx;
                 if (pix < last_pix) {
                     uint32_t v;
