@@ -581,3 +581,31 @@ def test_enhance_matches_independent_python_port(oracle):
     fin = np.isfinite(want) & (want != 0)
     assert fin.sum() > 150
     assert np.max(np.abs(got[fin] - want[fin]) / np.abs(want[fin])) < 2e-6
+
+
+def test_fastdiv24_formula_is_exact_on_its_domain():
+    """csrc/kde_device_math.h make_fastdiv24 / fastdiv24 (K7's x / wx, y / wy, label / cols; K1's workgroup -> tile):
+    with l = ceil(log2 d), m = floor(2^(24+l) / d) + 1, floor(x * m / 2^(24+l)) == x // d for every 0 <= x < 2^24.
+    Checked here on the multiples of d and their neighbours (where a wrong quotient would show first), on random x, and
+    exhaustively for small d."""
+    rng = np.random.default_rng(0)
+
+    def magic(d):
+        l = 0
+        while (1 << l) < d:
+            l += 1
+        return ((1 << (24 + l)) // d + 1, 24 + l)
+
+    ds = list(range(1, 300)) + [int(v) for v in rng.integers(300, 1 << 24, 300)] + [(1 << 24) - 1, 1 << 23, (1 << 23) + 1]
+    for d in ds:
+        m, sh = magic(d)
+        assert m < (1 << 32)
+        k = np.arange(0, (1 << 24) // d + 1, max(1, ((1 << 24) // d) // 4096), dtype=np.uint64)
+        xs = np.concatenate([k * d, k * d + (d - 1), np.maximum(k * d, 1) - 1, rng.integers(0, 1 << 24, 4096).astype(np.uint64),
+                             np.array([0, (1 << 24) - 1], np.uint64)])
+        xs = xs[xs < (1 << 24)]
+        assert np.array_equal((xs * np.uint64(m)) >> np.uint64(sh), xs // np.uint64(d)), d
+    for d in (1, 2, 3, 5, 7, 20, 96):
+        m, sh = magic(d)
+        xs = np.arange(1 << 24, dtype=np.uint64)
+        assert np.array_equal((xs * np.uint64(m)) >> np.uint64(sh), xs // np.uint64(d)), d
