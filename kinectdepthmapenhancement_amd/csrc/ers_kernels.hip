@@ -350,6 +350,7 @@ struct EnhDev {
     int width, height, window;
     float color_sigma, depth_sigma;
     float exp_zero;   // exp(-x) == 0 in binary32 iff x >= exp_zero
+    KDE_STAGE(float* stage_avg; float* stage_dev;)      // tools/hooks/libkde_hip_stage.so only
 };
 
 __global__ __launch_bounds__(kThreads) void enhance_kernel(EnhDev a)
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(kThreads) void enhance_kernel(EnhDev a)
             }
         }
     float result = 0.0f;
+    KDE_STAGE(if (a.stage_avg) a.stage_avg[(size_t)y * a.width + x] = weight > 0.0f ? w_average / weight : __builtin_nanf("");)
     if (weight > 0.0f) {
         w_average /= weight;
         // pass 2: mean absolute deviation over the same taps (.cu:143-156)
@@ -427,6 +429,7 @@ __global__ __launch_bounds__(kThreads) void enhance_kernel(EnhDev a)
                 }
             }
         if (count != 0) deviation /= (float)count;
+        KDE_STAGE(if (a.stage_dev) a.stage_dev[(size_t)y * a.width + x] = deviation;)
         // .cu:171: 5.0 is a double literal, pow(float,float) is float
         const float adaptive_sigma = (float)(5.0 * (double)deviation / (double)(w_average * w_average));
         // pass 3: all valid taps, colour sigma mutating per valid tap in raster order (.cu:158-195)
@@ -494,6 +497,7 @@ struct Enh7Dev {
     float ls[49];     // log2 of the spatial table
     float tinv[50];   // [k]: log2(e) / (2 c_k^2), +inf where the denominator underflows to 0
     float tthr[50];   // [k]: -(smallest cd with fl(cd / (2 c_k^2)) >= x0)
+    KDE_STAGE(float* stage_avg; float* stage_dev;)      // tools/hooks/libkde_hip_stage.so only
 };
 
 __device__ __forceinline__ uint32_t dot4u(uint32_t a, uint32_t b) { return __builtin_amdgcn_udot4(a, b, 0u, false); }
@@ -557,6 +561,7 @@ __global__ __launch_bounds__(kThreads) void enhance7_kernel(const Enh7Dev a)
             wgt += f;
         }
     float result = 0.0f;
+    KDE_STAGE(if (a.stage_avg) a.stage_avg[p] = wsum / wgt;)
     if (wgt > 0.0f) {
         const float wavg = wsum / wgt;
         // ---- pass 2: mean absolute deviation over the same taps (.cu:143-156) ---------------------------
@@ -572,6 +577,7 @@ __global__ __launch_bounds__(kThreads) void enhance7_kernel(const Enh7Dev a)
                 count += m ? 1 : 0;
             }
         if (count != 0) deviation /= (float)count;
+        KDE_STAGE(if (a.stage_dev) a.stage_dev[p] = deviation;)
         // .cu:171: 5.0 is a double literal, pow(float,float) is float
         const float asig = (float)(5.0 * (double)deviation / (double)(wavg * wavg));
         const float den_a = 2 * (asig * asig);
@@ -652,6 +658,7 @@ struct Enh7PkDev {
     __attribute__((aligned(8))) float lsp[98];  // [(row*7 + unit)*2 + pixel of the pair]: log2 of the spatial table
     float tinv[50];                             // finite
     float tthr[50];
+    KDE_STAGE(float* stage_avg; float* stage_dev; unsigned* stage_counters; int stage_force;)   // libkde_hip_stage.so only
 };
 
 __device__ __forceinline__ e_f2 e_fma(e_f2 a, e_f2 b, e_f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -764,6 +771,11 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
             tile_small_a = a.kfree < 50 && (denb == 0.0f || (1.0f / denb >= a.exp_zero * 1.001f && 1.4426950408889634f / denb >= tl * 1.001f));
         }
     }
+    KDE_STAGE(if (a.stage_force) { tile_small_a = false; tile_no_drule = false; })
+    KDE_STAGE(if (a.stage_counters && tid == 0) {
+        atomicAdd(&a.stage_counters[tile_small_a ? 4 : 5], 1u);
+        atomicAdd(&a.stage_counters[tile_no_drule ? 6 : 7], 1u);
+    })
 
     const int tx = tid % kE7BX, ty = tid / kE7BX;
     const int xb = x0 + 2 * tx, y = y0 + ty;
@@ -847,6 +859,7 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
     const e_f2 wavg = e_f2{wsum.x / wgt.x, wsum.y / wgt.y};    // IEEE: the integer skip thresholds below depend on it
     e_f2 inv_a = e_bcast(3.0e38f), nthr_a = e_bcast(-1.0f);     // values of a provably small adaptive sigma
     bool flat[2] = {false, false};
+    KDE_STAGE(float stage_dev2[2] = {0.0f, 0.0f}; bool stage_dev_done = false;)
     auto adaptive_sigma = [&]() {
         e_f2 dev = e_bcast(0.0f), cnt = e_bcast(0.0f);
 #pragma unroll 1
@@ -867,6 +880,7 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
         for (int h = 0; h < 2; h++) {
             float deviation = dev[h];
             if (cnt[h] != 0.0f) deviation /= cnt[h];
+            KDE_STAGE(stage_dev2[h] = deviation; stage_dev_done = true;)
             // 5.0 is a double literal, pow(float,float) is float
             const float asig = (float)(5.0 * (double)deviation / (double)(wavg[h] * wavg[h]));
             const float den_a = 2 * (asig * asig);
@@ -1035,6 +1049,20 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
     }
     a.out[p] = res[0];
     if (has1) a.out[p + 1] = res[1];
+    KDE_STAGE(if (a.stage_avg) {
+        a.stage_avg[p] = wavg.x;
+        if (has1) a.stage_avg[p + 1] = wavg.y;
+    })
+    KDE_STAGE(if (a.stage_dev) {
+        if (!stage_dev_done) {        // the product path never needed this pixel's deviation: form it for the dump only
+            const e_f2 keep_inv = inv_a, keep_thr = nthr_a;
+            const bool keep_flat[2] = {flat[0], flat[1]};
+            adaptive_sigma();
+            inv_a = keep_inv; nthr_a = keep_thr; flat[0] = keep_flat[0]; flat[1] = keep_flat[1];
+        }
+        a.stage_dev[p] = stage_dev2[0];
+        if (has1) a.stage_dev[p + 1] = stage_dev2[1];
+    })
 }
 
 }  // namespace
@@ -1136,6 +1164,8 @@ int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bg
         }
         // first rank from which every threshold is 1 (the sigmas only shrink with the rank: once 1, always 1)
         for (int k = 49; k >= 1 && d.tthr[k] >= -1.0f; k--) d.kfree = k;
+        KDE_STAGE(d.stage_avg = g_stage.ers_avg; d.stage_dev = g_stage.ers_dev; d.stage_counters = g_stage.counters;
+                  d.stage_force = g_stage.force_full_rules;)
         hipLaunchKernelGGL(enhance7_pk_kernel, dim3(ceil_div(width, kE7BX * 2) * ceil_div(height, kE7BY)),
                            dim3(kE7BX * kE7BY), 0, s, d);
         KDE_HIP_TRY(hipGetLastError());
@@ -1181,11 +1211,16 @@ int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bg
                 d.tthr[k] = -(float)lo;
             }
         }
+        KDE_STAGE(d.stage_avg = g_stage.ers_avg; d.stage_dev = g_stage.ers_dev;)
         hipLaunchKernelGGL(enhance7_kernel, dim3(ceil_div(width, kTileX), ceil_div(height, kTileY)), dim3(kThreads), 0, s, d);
         KDE_HIP_TRY(hipGetLastError());
         return KDE_OK;
     }
-    EnhDev d{rd, bgr, labels, s_eff, out, width, height, window, color_sigma, depth_sigma, exp_zero};
+    EnhDev d;
+    memset(&d, 0, sizeof(d));
+    d.rd = rd; d.bgr = bgr; d.labels = labels; d.s_eff = s_eff; d.out = out; d.width = width; d.height = height;
+    d.window = window; d.color_sigma = color_sigma; d.depth_sigma = depth_sigma; d.exp_zero = exp_zero;
+    KDE_STAGE(d.stage_avg = g_stage.ers_avg; d.stage_dev = g_stage.ers_dev;)
     const int R = window / 2;
     const size_t lds = (size_t)(kTileX + 2 * R) * (kTileY + 2 * R) * 12 + (size_t)window * window * 4;
     hipLaunchKernelGGL(enhance_kernel, dim3(ceil_div(width, kTileX), ceil_div(height, kTileY)), dim3(kThreads), lds, s, d);

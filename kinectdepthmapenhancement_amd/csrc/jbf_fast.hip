@@ -51,6 +51,7 @@ struct FastArgs {
     float t2_skip;   // t_skip^2 (3e38 when nothing is skipped) for the packed-arithmetic form of the rule
     int cd_skip;     // colour factor skipped when cd >= cd_skip
     int vec4;        // width % 4 == 0 and 16-byte aligned frames: the packed kernels load 4-pixel groups
+    KDE_STAGE(float* stage_avg; unsigned* stage_counters; int stage_force;)   // tools/hooks/libkde_hip_stage.so only
     // log2 of the spatial table (zeros of the table -> factor skipped -> log2 = 0).  Scalar kernels read
     // tab[i*WIN + j]; packed kernels read the pair (ls[i][j of p0], ls[i][j of p1]) of unit u at
     // tab[(i*WIN + u)*2 .. +1], so the addend of the argument fma is one aligned SGPR pair.
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_fast_kernel(const FastArgs a)
         float r = 0.0f;
         if (wgt[k] > 0.0f) r = (den[k] == 0.0f) ? 0.0f : num[k] / den[k];
         if (xb + k < a.width) o[k] = r;
+        KDE_STAGE(if (a.stage_avg && xb + k < a.width) a.stage_avg[frame + (size_t)y * a.width + xb + k] = c2[k];)
     }
 }
 
@@ -430,6 +432,15 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         const float range = __uint_as_float(s_stat[1]) - __uint_as_float(s_stat[0]);       // -inf when no valid depth was staged
         tile_d = !(range * a.sd * 1.0001f < a.t_skip);
     }
+    KDE_STAGE(if (a.stage_force) { tile_c = CSKIP; tile_d = true; })
+    KDE_STAGE(if (a.stage_counters && tid == 0) {
+        // the body the dispatch below picks for this tile: bit 0 = colour rule compiled in, bit 1 = depth rule
+        int body;
+        if constexpr (!ELIDE) body = (CSKIP ? 1 : 0) + 2;
+        else if constexpr (WIN >= 15) body = ((CSKIP && tile_c) || tile_d) ? (CSKIP ? 1 : 0) + 2 : 0;
+        else body = ((CSKIP && tile_c) ? 1 : 0) + (tile_d ? 2 : 0);
+        atomicAdd(&a.stage_counters[body], 1u);
+    })
 
     const int tx = tid % BX, ty = tid / BX;
     const int xb = x0 + tx * PX, y = y0 + ty;
@@ -601,6 +612,11 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         if (wgt[pp].y > 0.0f) r1 = (den[pp].y == 0.0f) ? 0.0f : num[pp].y * __builtin_amdgcn_rcpf(den[pp].y);
         if (xb + 2 * pp >= 0 && xb + 2 * pp < a.width) op[2 * pp] = r0;
         if (xb + 2 * pp + 1 < a.width) op[2 * pp + 1] = r1;
+        KDE_STAGE(if (a.stage_avg) {
+            float* sp = a.stage_avg + frame + (size_t)y * a.width + xb;
+            if (xb + 2 * pp >= 0 && xb + 2 * pp < a.width) sp[2 * pp] = c2[pp].x;
+            if (xb + 2 * pp + 1 < a.width) sp[2 * pp + 1] = c2[pp].y;
+        })
     }
 }
 
@@ -714,6 +730,7 @@ int launch_jbf_fast(const JbfLaunch& l, int variant, const float* table_host, hi
     a.cd_skip = l.cd_skip;
     a.vec4 = (l.width % 4 == 0) && ((reinterpret_cast<uintptr_t>(l.depth) & 15u) == 0) &&
              ((reinterpret_cast<uintptr_t>(l.guide) & 3u) == 0);
+    KDE_STAGE(a.stage_avg = g_stage.jbf_avg; a.stage_counters = g_stage.counters; a.stage_force = g_stage.force_full_rules;)
     const int W = l.window, HALF = (W - 1) / 2;
     auto lg = [&](int i, int j) {
         const float sv = table_host[i * W + j];

@@ -54,6 +54,7 @@ struct JbfDev {
     int color_on, depth_on;
     int cd_skip;
     float d2_skip;
+    KDE_STAGE(float* stage_avg;)      // tools/hooks/libkde_hip_stage.so only
 };
 
 __global__ __launch_bounds__(kThreads) void jbf_generic_kernel(JbfDev a)
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(kThreads) void jbf_generic_kernel(JbfDev a)
         result = (denominator == 0.0f) ? 0.0f : numerator / denominator;
     }
     a.out[frame + (size_t)y * a.width + x] = result;
+    KDE_STAGE(if (a.stage_avg) a.stage_avg[frame + (size_t)y * a.width + x] = weight > 0.0f ? w_average : __builtin_nanf("");)
 }
 
 // --------------------------------------------------------------------------------------------
@@ -464,6 +466,7 @@ int launch_jbf(const JbfLaunch& a, hipStream_t s)
     d.depth_on = a.depth_sigma != 0.0f;
     d.cd_skip = a.cd_skip;
     d.d2_skip = a.d2_skip;
+    KDE_STAGE(d.stage_avg = g_stage.jbf_avg;)
     const int R = a.window / 2;
     const size_t lds = (size_t)(kTileX + 2 * R) * (kTileY + 2 * R) * 8 + (size_t)a.window * a.window * 4;
     dim3 grid(ceil_div(a.width, kTileX), ceil_div(a.height, kTileY), a.n);

@@ -19,9 +19,26 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
+#ifdef KDE_STAGE_HOOKS
+StageCtl g_stage = {nullptr, nullptr, nullptr, nullptr, 0};
+#endif
+
 }  // namespace kde
 
 using namespace kde;
+
+#ifdef KDE_STAGE_HOOKS
+// include/kde_test_hooks.h: exists only in tools/hooks/libkde_hip_stage.so
+extern "C" int kde_stage_set(float* jbf_avg_dev, float* ers_avg_dev, float* ers_dev_dev, unsigned* counters_dev, int force_full_rules)
+{
+    g_stage.jbf_avg = jbf_avg_dev;
+    g_stage.ers_avg = ers_avg_dev;
+    g_stage.ers_dev = ers_dev_dev;
+    g_stage.counters = counters_dev;
+    g_stage.force_full_rules = force_full_rules;
+    return KDE_OK;
+}
+#endif
 
 // =====================================================================================================
 // library

@@ -38,6 +38,24 @@ int fail(int code, const char* fmt, ...);   // records the message for kde_last_
         if (!(cond)) return ::kde::fail(KDE_ERR_INVALID, __VA_ARGS__); \
     } while (0)
 
+// ---- stage hooks -----------------------------------------------------------------------------
+// Compiled ONLY into tools/hooks/libkde_hip_stage.so (-DKDE_STAGE_HOOKS, include/kde_test_hooks.h): the same
+// sources as the product library plus per-pixel dumps of K1's / K10's intermediate stages, a switch that forces the
+// full-rule bodies, and counters of the body each tile ran.  The product library contains none of it.
+#ifdef KDE_STAGE_HOOKS
+struct StageCtl {
+    float* jbf_avg;          // [n][H][W]: first-pass average of K1 as pass 2 uses it (NaN where the sum of weights is 0)
+    float* ers_avg;          // [H][W]: K10 pass-1 average (NaN where the sum of weights is 0)
+    float* ers_dev;          // [H][W]: K10 pass-2 mean absolute deviation (undefined where ers_avg is NaN)
+    unsigned* counters;      // [8]: K1 tiles per body (colour rule + 2 * depth rule), K10 tiles (small-a, not, no depth rule, depth rule)
+    int force_full_rules;    // != 0: every tile runs the body with both Q1 rules / the per-pixel deviation pass
+};
+extern StageCtl g_stage;
+#define KDE_STAGE(...) __VA_ARGS__
+#else
+#define KDE_STAGE(...)
+#endif
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

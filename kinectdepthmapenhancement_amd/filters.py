@@ -61,10 +61,11 @@ class _Handle:
 
     def __init__(self):
         self._h = C.c_void_p()
+        self._owner_lib = lib()     # a handle is destroyed by the library that created it
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            getattr(lib(), self._destroy)(self._h)
+            getattr(self._owner_lib, self._destroy)(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

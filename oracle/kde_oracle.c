@@ -211,7 +211,7 @@ static double n_significant(const double* w, const uint8_t* use, int n, double t
  * caller is going to probe (widens the threshold band, see thr_band); *tol_out: that band's half-width. */
 static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double avg_rel, double thr_scale,
                          double und_scale, int* band, double* n_eff, int q1, double centre1, int q2, double centre2,
-                         double* den_out, double band_eps, double* tol_out)
+                         double* den_out, double band_eps, double* tol_out, const double* avg_abs)
 {
     const double U = kUnder * und_scale;
     double wa = 0.0, wt = 0.0;
@@ -228,7 +228,7 @@ static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double av
     if (n_eff) *n_eff = n_significant(t->base, NULL, t->n, wt, U);
     const double tol = depth_on ? thr_band(band_eps, wa / wt, dden) : 1.5e-4;
     if (tol_out) *tol_out = tol;
-    wa = wa / wt * (1.0 + avg_rel);
+    wa = avg_abs ? *avg_abs : wa / wt * (1.0 + avg_rel);      /* avg_abs: the stage-wise check evaluates pass 2 at a GIVEN average */
     double nu = 0.0, de = 0.0;
     for (int k = 0; k < t->n; k++) {
         double f = t->base[k];
@@ -354,13 +354,13 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                 int band = 0;
                 double n_eff = 1.0, dens[2] = {0.0, 0.0};
                 double tol = 1.5e-4;
-                const double r0 = jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL);
+                const double r0 = jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL, NULL);
                 /* rounding of the float32 sums behind the average: the first-order bound of recursive summation over
                  * the taps that can round at all (see n_significant), plus the products and the division */
                 const double eps_avg = (4.0 + 0.5 * n_eff) * 1.1920928955078125e-7;
                 env_add(&e, r0);
-                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol));
-                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, -eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol));
+                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol, NULL));
+                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, -eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol, NULL));
                 if (band) {
                     flag |= 2;
                     for (int a = -1; a <= 1; a++)
@@ -368,7 +368,7 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                             for (int c = -1; c <= 1; c++) {
                                 int dummy = 0;
                                 env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, a * eps_avg, 1.0 + b * tol,
-                                                       1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL));
+                                                       1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, NULL));
                             }
                 }
                 /* a sum of weights so small that the 2^-149 grid is within 1e-6 of it: the float32 value is
@@ -380,7 +380,7 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                         for (int b = (qb ? -1 : 0); b <= (qb ? 1 : 0); b++) {
                             if (a == 0 && b == 0) continue;
                             int dummy = 0;
-                            env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &dummy, NULL, a, wa0, b, r0, NULL, 0.0, NULL));
+                            env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &dummy, NULL, a, wa0, b, r0, NULL, 0.0, NULL, NULL));
                         }
                 }
                 env_add(&e, (double)out);
@@ -397,6 +397,164 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                     env->hi[p] = e.hi;
                 }
             }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Stage-wise check of K1 (see okde_stage in kde_oracle.h).  The composite filter is ill-conditioned only THROUGH its
+ * first-pass average; each pass by itself is well-conditioned.  So, given the average an implementation actually used:
+ *   pass 1  its average against the binary64 average, within the first-order bound of a float32 evaluation;
+ *   pass 2  the binary64 value of JointBilateralFilter.cu:43-78 evaluated AT THAT AVERAGE (the reference's float32
+ *           decisions, its tap set), which the implementation's final value must match to 1e-4.
+ * Only pixels with a tap ON a Q1 decision at that very average (BAND), or whose sums of weights lie on the float32
+ * denormal grid (GRID), get an interval instead: both outcomes of the open decision, evaluated at the same average.
+ * ---------------------------------------------------------------------------------------- */
+static void jbf_collect_taps(int width, int height, const float* depth, const uint8_t* guide, const float* spatial,
+                             int window_size, float color_sigma, int x, int y, jbf_taps* t)
+{
+    const int hw = window_size / 2;
+    const uint8_t* cc = guide + ((size_t)y * width + x) * 3;
+    const double cden = 2.0 * (double)color_sigma * (double)color_sigma;
+    t->n = 0;
+    for (int i = -hw; i <= hw; i++)
+        for (int j = -hw; j <= hw; j++) {
+            int xj = x + j, yi = y + i;
+            if (xj >= 0 && xj < width && yi >= 0 && yi < height && depth[(size_t)yi * width + xj] > 50.0f &&
+                t->n < OKDE_MAXTAPS) {
+                float color_diff = color_diff3(cc, guide + ((size_t)yi * width + xj) * 3);
+                double f = 1.0;
+                float sv = spatial[(i + hw) * window_size + (j + hw)];
+                if (sv != 0.0f) f *= (double)sv;
+                /* the colour factor is skipped exactly when the float32 code skips it (.cu:32) */
+                if (color_sigma != 0.0f && expf(-color_diff / (2 * (color_sigma * color_sigma))) != 0.0f)
+                    f *= exp(-(double)color_diff / cden);
+                t->d[t->n] = (double)depth[(size_t)yi * width + xj];
+                t->base[t->n] = f;
+                t->n++;
+            }
+        }
+}
+
+/* pass 1 of the float32 restatement (.cu:16-41), for the stage check's "own average" mode */
+static float jbf_pass1_f32(int width, int height, const float* depth, const uint8_t* guide, const float* spatial,
+                           int window_size, float color_sigma, int x, int y)
+{
+    const int hw = window_size / 2;
+    const uint8_t* cc = guide + ((size_t)y * width + x) * 3;
+    float w_average = 0.0f, weight = 0.0f;
+    for (int i = -hw; i <= hw; i++)
+        for (int j = -hw; j <= hw; j++) {
+            int xj = x + j, yi = y + i;
+            if (xj >= 0 && xj < width && yi >= 0 && yi < height && depth[(size_t)yi * width + xj] > 50.0f) {
+                float color_diff = color_diff3(cc, guide + ((size_t)yi * width + xj) * 3);
+                float color_filter = 0.0f;
+                if (color_sigma != 0.0f) color_filter = expf(-color_diff / (2 * (color_sigma * color_sigma)));
+                float filter = 1.0f;
+                float s = spatial[(i + hw) * window_size + (j + hw)];
+                if (s != 0.0f) filter *= s;
+                if (color_filter != 0.0f) filter *= color_filter;
+                w_average += depth[(size_t)yi * width + xj] * filter;
+                weight += filter;
+            }
+        }
+    return weight > 0.0f ? w_average / weight : NAN;
+}
+
+/* Relative bound on |avg32 - avg64| for a faithful float32 evaluation of sum(d f) / sum(f) over weights w[] (use[]
+ * selects taps): recursive summation over the taps that can round the sums ((n - 1) / 2 ulps, see n_significant),
+ * products and the division (4 ulps), PLUS the weights' own float32 noise: a weight exp(-x) S formed in float32 is off
+ * by up to about (32 + 2 x) 2^-24 relative (x rounded before the exponential: x 2^-24; the exponential: 2 ulps; the
+ * product with S; in the log2-domain kernels the rounding of the argument log2 S + 24 - x log2 e, its table entry and
+ * the scale of x), and that noise is not common to the taps: it moves the average by sum f e |d - avg| / sum f. */
+static double avg_bound(const double* d, const double* w, const uint8_t* use, int n, double under, double wt, double avg)
+{
+    const double u = 0x1p-24;
+    double noise = 0.0;
+    for (int k = 0; k < n; k++) {
+        if ((use && !use[k]) || !(w[k] > under)) continue;
+        const double xk = w[k] < 1.0 ? -log(w[k]) : 0.0;
+        noise += w[k] * (32.0 + 2.0 * xk) * u * fabs(d[k] - avg);
+    }
+    const double nsig = n_significant(w, use, n, wt, under);
+    return (4.0 + 0.5 * nsig) * 2.0 * u + (avg != 0.0 ? noise / (wt * fabs(avg)) : 0.0);
+}
+
+void okde_jbf_stage(int width, int height, const float* depth, const uint8_t* guide, const float* spatial,
+                    int window_size, float color_sigma, float depth_sigma, const float* avg_in, const okde_stage* out)
+{
+    const double dden = 2.0 * (double)depth_sigma * (double)depth_sigma;
+    const int don = depth_sigma != 0.0f;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            const size_t p = (size_t)y * width + x;
+            jbf_taps t;
+            jbf_collect_taps(width, height, depth, guide, spatial, window_size, color_sigma, x, y, &t);
+            uint8_t flag = 0;
+            /* ---- pass 1 in binary64 ---- */
+            int band1 = 0;
+            double wa = 0.0, wt = 0.0;
+            for (int k = 0; k < t.n; k++) {
+                const double f = t.base[k];
+                if (fabs(f / kUnder - 1.0) <= 5e-4) band1 = 1;
+                if (f <= kUnder) continue;
+                wa += t.d[k] * f;
+                wt += f;
+            }
+            const float a32 = avg_in ? avg_in[p] : jbf_pass1_f32(width, height, depth, guide, spatial, window_size, color_sigma, x, y);
+            if (out->avg32) out->avg32[p] = a32;
+            double avg64 = 0.0, tol_avg = INFINITY;
+            const int grid1 = wt > 0.0 && wt < 0x1p-110;
+            if (wt > 0.0) {
+                avg64 = wa / wt;
+                if (!band1 && !grid1) tol_avg = avg_bound(t.d, t.base, NULL, t.n, kUnder, wt, avg64);
+            }
+            if (out->avg64) out->avg64[p] = avg64;
+            if (out->avg_tol) out->avg_tol[p] = tol_avg;
+            env_acc e = {0.0, 0.0, 0, 0};
+            double fin = 0.0;
+            if (!(wt > 0.0) && !band1) {
+                /* no weight at all: the output is 0 (.cu:39) and there is no average */
+                flag |= OKDE_STAGE_NOWEIGHT;
+                if (a32 == a32) flag |= OKDE_STAGE_MISMATCH;
+            } else if (a32 != a32) {
+                /* the implementation saw no weight; admissible only when a weight sits on the underflow decision */
+                if (band1) flag |= OKDE_STAGE_BAND | OKDE_STAGE_ZERO_OK;
+                else flag |= OKDE_STAGE_MISMATCH;
+                e.zero = 1;
+            } else {
+                /* ---- pass 2 in binary64 at the given average ---- */
+                const double a = (double)a32;
+                int band2 = 0;
+                double dens[2] = {0.0, 0.0}, tol = 1.5e-4;
+                fin = jbf_eval64(&t, dden, don, 0.0, 1.0, 1.0, &band2, NULL, 0, 0.0, 0, 0.0, dens, 0.0, &tol, &a);
+                env_add(&e, fin);
+                if (band1 || band2) {
+                    flag |= OKDE_STAGE_BAND;
+                    for (int b = -1; b <= 1; b++)
+                        for (int c = -1; c <= 1; c++) {
+                            int dummy = 0;
+                            env_add(&e, jbf_eval64(&t, dden, don, 0.0, 1.0 + b * tol, 1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0,
+                                                   0.0, NULL, 0.0, NULL, &a));
+                        }
+                }
+                if (grid1 || (dens[1] > 0.0 && dens[1] < 0x1p-110)) {
+                    /* sums on the float32 denormal grid: bracket the quantisation noise of the weights (see quantised()) */
+                    flag |= OKDE_STAGE_BAND | OKDE_STAGE_GRID;
+                    for (int q = -1; q <= 1; q += 2) {
+                        int dummy = 0;
+                        env_add(&e, jbf_eval64(&t, dden, don, 0.0, 1.0, 1.0, &dummy, NULL, 0, 0.0, q, fin, NULL, 0.0, NULL, &a));
+                    }
+                    e.zero = 1;
+                }
+            }
+            if (!e.nonzero) e.lo = e.hi = 0.0;
+            if (e.zero) flag |= OKDE_STAGE_ZERO_OK;
+            if (out->fin64) out->fin64[p] = fin;
+            if (out->lo) out->lo[p] = e.lo;
+            if (out->hi) out->hi[p] = e.hi;
+            out->flags[p] = flag;
         }
     }
 }
@@ -943,7 +1101,7 @@ typedef struct {
  * Returns the result (0 = "output is 0", NaN = the Q6 quirk); *band |= 1 when a tap sits in a decision band. */
 static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, int depth_on, float a, double avg_rel,
                          double thr_scale, double und_scale, int* band, double* n_eff, int q1, double centre1, int q2,
-                         double centre2, double* den_out, double band_eps, double* tol_out)
+                         double centre2, double* den_out, double band_eps, double* tol_out, const double* avg_abs)
 {
     const double U = kUnder * und_scale;
     double wa = 0.0, wt = 0.0;
@@ -966,7 +1124,7 @@ static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, i
     if (n_eff) *n_eff = n_significant(w1, NULL, t->n, wt, 0.0);
     const double tol = depth_on ? thr_band(band_eps, wa / wt, dden) : 1.5e-4;     /* see jbf_eval64 */
     if (tol_out) *tol_out = tol;
-    wa = wa / wt * (1.0 + avg_rel);
+    wa = avg_abs ? *avg_abs : wa / wt * (1.0 + avg_rel);      /* avg_abs: see jbf_eval64 */
     float cs = color_sigma_in;
     double nu = 0.0, de = 0.0;
     for (int k = 0; k < t->n; k++) {
@@ -1118,11 +1276,11 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                 int band = 0;
                 double n_eff = 1.0, dens[2] = {0.0, 0.0};
                 double tol = 1.5e-4;
-                const double r0 = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL);
+                const double r0 = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL, NULL);
                 const double eps_avg = (4.0 + 0.5 * n_eff) * 1.1920928955078125e-7;     /* as in okde_jbf_kernel */
                 for (int v = 0; v < nalt; v++)
                     for (int a = -1; a <= 1; a++) {
-                        const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol);
+                        const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol, NULL);
                         if (r != r) nan_ok = 1;
                         else env_add(&e, r);
                     }
@@ -1134,7 +1292,7 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                                 for (int c = -1; c <= 1; c++) {
                                     int dummy = 0;
                                     const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg,
-                                                                1.0 + b * tol, 1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL);
+                                                                1.0 + b * tol, 1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, NULL);
                                     if (r != r) nan_ok = 1;
                                     else env_add(&e, r);
                                 }
@@ -1146,7 +1304,7 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                         for (int b = (qb ? -1 : 0); b <= (qb ? 1 : 0); b++) {
                             if (a == 0 && b == 0) continue;
                             int dummy = 0;
-                            const double r = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &dummy, NULL, a, r0, b, r0, NULL, 0.0, NULL);
+                            const double r = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &dummy, NULL, a, r0, b, r0, NULL, 0.0, NULL, NULL);
                             if (r != r) nan_ok = 1;
                             else env_add(&e, r);
                         }
@@ -1167,6 +1325,176 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                     env->hi[p] = e.hi;
                 }
             }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Stage-wise check of K10 (see okde_stage / okde_jbf_stage): given the label-restricted average AND the mean absolute
+ * deviation an implementation used, pass 1 and pass 2 are checked against binary64 with first-order float32 bounds,
+ * and pass 3 (EdgeRefinedSuperpixel.cu:158-200: adaptive sigma from exactly those two numbers by the reference's own
+ * expression, the mutating colour sigma with its float32 decisions) is evaluated in binary64 from them.
+ * ---------------------------------------------------------------------------------------- */
+static void ers_collect_taps(int width, int height, const float* rd, const uint8_t* bgr, const int32_t* refined_labels,
+                             const float* spatial, int window_size, int x, int y, ers_taps* t)
+{
+    const int hw = window_size / 2;
+    const size_t p = (size_t)y * width + x;
+    const uint8_t* cc = bgr + p * 3;
+    t->n = 0;
+    for (int i = -hw; i <= hw; i++)
+        for (int j = -hw; j <= hw; j++) {
+            int xj = x + j, yi = y + i;
+            if (xj >= 0 && xj < width && yi >= 0 && yi < height && t->n < OKDE_MAXTAPS) {
+                const size_t q = (size_t)yi * width + xj;
+                if (rd[q] > 50.0f) {
+                    const float sv = spatial[(i + hw) * window_size + (j + hw)];
+                    t->d[t->n] = (double)rd[q];
+                    t->s[t->n] = sv != 0.0f ? (double)sv : 1.0;
+                    t->cd[t->n] = color_diff3(cc, bgr + q * 3);
+                    t->same[t->n] = refined_labels[p] == refined_labels[q];
+                    t->n++;
+                }
+            }
+        }
+}
+
+/* passes 1 and 2 of the float32 restatement (.cu:116-156), for the stage check's "own values" mode */
+static void ers_pass12_f32(const ers_taps* t, float color_sigma, float* avg_out, float* dev_out)
+{
+    float w_average = 0.0f, weight = 0.0f;
+    for (int k = 0; k < t->n; k++) {
+        if (!t->same[k]) continue;
+        float color_filter = 0.0f;
+        if (color_sigma != 0.0f) color_filter = expf(-t->cd[k] / (2 * (color_sigma * color_sigma)));
+        float filter = 1.0f;
+        filter *= (float)t->s[k];
+        if (color_filter != 0.0f) filter *= color_filter;
+        w_average += (float)t->d[k] * filter;
+        weight += filter;
+    }
+    *avg_out = NAN;
+    *dev_out = 0.0f;
+    if (!(weight > 0.0f)) return;
+    w_average /= weight;
+    float deviation = 0.0f;
+    int count = 0;
+    for (int k = 0; k < t->n; k++)
+        if (t->same[k]) {
+            deviation += fabsf((float)t->d[k] - w_average);
+            count++;
+        }
+    if (count != 0) deviation /= (float)count;
+    *avg_out = w_average;
+    *dev_out = deviation;
+}
+
+void okde_ers_stage(int width, int height, const float* rd, const uint8_t* bgr, const int32_t* refined_labels,
+                    const float* spatial, int window_size, float color_sigma_in, float depth_sigma,
+                    const float* avg_in, const float* dev_in, const okde_stage* out)
+{
+    const double dden = 2.0 * (double)depth_sigma * (double)depth_sigma;
+    const int don = depth_sigma != 0.0f;
+    const double cden = 2.0 * (double)color_sigma_in * (double)color_sigma_in;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            const size_t p = (size_t)y * width + x;
+            ers_taps t;
+            ers_collect_taps(width, height, rd, bgr, refined_labels, spatial, window_size, x, y, &t);
+            uint8_t flag = 0;
+            /* ---- pass 1 in binary64 (same-label taps) ---- */
+            double w1[OKDE_MAXTAPS];
+            int band1 = 0, count = 0;
+            double wa = 0.0, wt = 0.0;
+            for (int k = 0; k < t.n; k++) {
+                w1[k] = 0.0;
+                if (!t.same[k]) continue;
+                count++;
+                double f = t.s[k];
+                if (color_sigma_in != 0.0f && expf(-t.cd[k] / (2 * (color_sigma_in * color_sigma_in))) != 0.0f)
+                    f *= exp(-(double)t.cd[k] / cden);
+                if (fabs(f / kUnder - 1.0) <= 5e-4) band1 = 1;
+                if (f <= kUnder) continue;
+                w1[k] = f;
+                wa += t.d[k] * f;
+                wt += f;
+            }
+            float a32, dev32;
+            if (avg_in) {
+                a32 = avg_in[p];
+                dev32 = dev_in[p];
+            } else {
+                ers_pass12_f32(&t, color_sigma_in, &a32, &dev32);
+            }
+            if (out->avg32) out->avg32[p] = a32;
+            if (out->dev32) out->dev32[p] = dev32;
+            double avg64 = 0.0, tol_avg = INFINITY;
+            const int grid1 = wt > 0.0 && wt < 0x1p-110;
+            if (wt > 0.0) {
+                avg64 = wa / wt;
+                if (!band1 && !grid1) tol_avg = avg_bound(t.d, w1, t.same, t.n, 0.0, wt, avg64);
+            }
+            if (out->avg64) out->avg64[p] = avg64;
+            if (out->avg_tol) out->avg_tol[p] = tol_avg;
+            env_acc e = {0.0, 0.0, 0, 0};
+            double fin = 0.0, dev64 = 0.0, tol_dev = INFINITY;
+            int nan_seen = 0;
+            if (!(wt > 0.0) && !band1) {
+                flag |= OKDE_STAGE_NOWEIGHT;
+                if (a32 == a32) flag |= OKDE_STAGE_MISMATCH;
+            } else if (a32 != a32) {
+                if (band1) flag |= OKDE_STAGE_BAND | OKDE_STAGE_ZERO_OK;
+                else flag |= OKDE_STAGE_MISMATCH;
+                e.zero = 1;
+            } else {
+                const double a = (double)a32;
+                /* ---- pass 2 in binary64 at the given average: mean |d - avg| over the same taps (.cu:143-156).  Each term
+                 * is one float32 subtraction (half an ulp of itself), the sum (count - 1) / 2 ulps, the division one ---- */
+                for (int k = 0; k < t.n; k++)
+                    if (t.same[k]) dev64 += fabs(t.d[k] - a);
+                if (count) dev64 /= (double)count;
+                tol_dev = (3.0 + 0.5 * (double)count) * 2.0 * 0x1p-24;
+                /* ---- pass 3 in binary64 from (average, deviation) as given; .cu:171 forms the adaptive sigma so: ---- */
+                const float adaptive = (float)(5.0 * (double)dev32 / (double)(a32 * a32));
+                int band3 = 0;
+                double dens[2] = {0.0, 0.0}, tol = 1.5e-4;
+                fin = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band3, NULL, 0, 0.0, 0, 0.0, dens,
+                                 0.0, &tol, &a);
+                if (fin != fin) nan_seen = 1;
+                else env_add(&e, fin);
+                if (band1 || band3) {
+                    flag |= OKDE_STAGE_BAND;
+                    for (int b = -1; b <= 1; b++)
+                        for (int c = -1; c <= 1; c++) {
+                            int dummy = 0;
+                            const double r = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0 + b * tol,
+                                                        1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, &a);
+                            if (r != r) nan_seen = 1;
+                            else env_add(&e, r);
+                        }
+                }
+                if ((grid1 || (dens[1] > 0.0 && dens[1] < 0x1p-110)) && fin == fin) {
+                    flag |= OKDE_STAGE_BAND | OKDE_STAGE_GRID;
+                    for (int q = -1; q <= 1; q += 2) {
+                        int dummy = 0;
+                        const double r = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &dummy, NULL, 0,
+                                                    0.0, q, fin, NULL, 0.0, NULL, &a);
+                        if (r != r) nan_seen = 1;
+                        else env_add(&e, r);
+                    }
+                    e.zero = 1;
+                }
+            }
+            if (!e.nonzero) e.lo = e.hi = 0.0;
+            if (e.zero) flag |= OKDE_STAGE_ZERO_OK;
+            if (nan_seen) flag |= OKDE_STAGE_NAN_OK;
+            if (out->dev64) out->dev64[p] = dev64;
+            if (out->dev_tol) out->dev_tol[p] = tol_dev;
+            if (out->fin64) out->fin64[p] = fin;
+            if (out->lo) out->lo[p] = e.lo;
+            if (out->hi) out->hi[p] = e.hi;
+            out->flags[p] = flag;
         }
     }
 }

@@ -75,6 +75,45 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                      const float* spatial, int window, float color_sigma, float depth_sigma,
                      float* filtered, const okde_env* env);
 
+/* ---- stage-wise parity (round 3) ------------------------------------------------------------------------------------
+ * K1 and K10 are ill-conditioned only THROUGH their first-pass average (and K10's deviation); each pass by itself is
+ * well-conditioned.  okde_jbf_stage / okde_ers_stage therefore take the intermediate values an implementation actually
+ * used -- the HIP kernels dump them through tools/hooks/libkde_hip_stage.so; with avg_in == NULL the float32 restatement's
+ * own are used (and returned in avg32 / dev32) -- and emit, per pixel:
+ *   avg64, avg_tol  binary64 first-pass average and the RELATIVE first-order bound of a faithful float32 evaluation of it
+ *                   (summation + the weights' own rounding, see avg_bound() in kde_oracle.c; INFINITY = not comparable:
+ *                   a pass-1 weight sits on the float32 underflow-to-zero decision, or the sum is on the denormal grid)
+ *   dev64, dev_tol  (K10) binary64 mean |d - avg| over the same-label taps AT the given average, relative bound
+ *   fin64           the last pass in binary64 evaluated AT the given average (and deviation), with the reference's
+ *                   float32 decisions: the implementation's final value must match it to 1e-4 unless flagged BAND
+ *   lo, hi          for BAND pixels the span of the results with the open decision(s) taken either way, at the same
+ *                   average; equal to fin64 elsewhere
+ *   flags           OKDE_STAGE_*                                                                                      */
+#define OKDE_STAGE_BAND 2       /* a tap sits within 1.5e-4 of the depth-factor underflow point at THIS average, or a weight
+                                   within 5e-4 of 2^-150: [lo, hi] applies instead of fin64 */
+#define OKDE_STAGE_ZERO_OK 8    /* 0 is one of the admissible results */
+#define OKDE_STAGE_NAN_OK 16    /* K10: the result (or one admissible result of a BAND pixel) is NaN (Q6) */
+#define OKDE_STAGE_GRID 32      /* a sum of weights below 2^-110: the reference holds such weights on the 2^-149 grid */
+#define OKDE_STAGE_NOWEIGHT 64  /* no tap has a weight: the output is 0 and there is no average (avg_in must be NaN) */
+#define OKDE_STAGE_MISMATCH 128 /* avg_in is NaN where weights exist or a number where none do: always an error */
+typedef struct {
+    float* avg32;       /* optional */
+    float* dev32;       /* optional, K10 */
+    double* avg64;
+    double* avg_tol;
+    double* dev64;      /* K10 */
+    double* dev_tol;    /* K10 */
+    double* fin64;
+    double* lo;
+    double* hi;
+    uint8_t* flags;     /* required */
+} okde_stage;
+void okde_jbf_stage(int width, int height, const float* depth, const uint8_t* guide_bgr, const float* spatial,
+                    int window, float color_sigma, float depth_sigma, const float* avg_in, const okde_stage* out);
+void okde_ers_stage(int width, int height, const float* refined_depth_in, const uint8_t* bgr,
+                    const int32_t* refined_labels, const float* spatial, int window, float color_sigma,
+                    float depth_sigma, const float* avg_in, const float* dev_in, const okde_stage* out);
+
 /* JointBilateralFilter::Process, JointBilateralFilter.cu:283-290 (K0 then K1).
  * presmooth_ksize <= -1000 disables the pre-smoothing (guide = colour). */
 void okde_jbf_process(int width, int height, const float* depth, const uint8_t* bgr,

@@ -130,6 +130,127 @@ def parity_check(got, ref, env=None, rtol=1e-4):
             "max_rel_flagged": float(rel[flagged].max()) if flagged.any() else 0.0}
 
 
+# ---- stage-wise parity (kde_oracle.h: okde_stage) -----------------------------------------------------------------
+class _CStage(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("avg32", "dev32", "avg64", "avg_tol", "dev64", "dev_tol", "fin64", "lo", "hi", "flags")]
+
+
+class Stage:
+    """Outputs of okde_jbf_stage / okde_ers_stage (see kde_oracle.h)."""
+    BAND, ZERO_OK, NAN_OK, GRID, NOWEIGHT, MISMATCH = 2, 8, 16, 32, 64, 128
+
+    def __init__(self, shape, with_dev=False):
+        self.shape = tuple(shape)
+        self.avg32 = np.zeros(shape, np.float32)
+        self.dev32 = np.zeros(shape, np.float32) if with_dev else None
+        self.avg64, self.avg_tol = np.zeros(shape, np.float64), np.zeros(shape, np.float64)
+        self.dev64 = np.zeros(shape, np.float64) if with_dev else None
+        self.dev_tol = np.zeros(shape, np.float64) if with_dev else None
+        self.fin64, self.lo, self.hi = (np.zeros(shape, np.float64) for _ in range(3))
+        self.flags = np.zeros(shape, np.uint8)
+        ptr = lambda a: None if a is None else a.ctypes.data
+        self._c = _CStage(ptr(self.avg32), ptr(self.dev32), ptr(self.avg64), ptr(self.avg_tol), ptr(self.dev64),
+                          ptr(self.dev_tol), ptr(self.fin64), ptr(self.lo), ptr(self.hi), ptr(self.flags))
+
+    def ref(self):
+        return C.byref(self._c)
+
+    @property
+    def band(self):
+        return (self.flags & self.BAND) != 0
+
+
+def jbf_stage(depth, guide, window=5, spatial_sigma=70.0, color_sigma=50.0, depth_sigma=20.0, avg_in=None) -> Stage:
+    """Stage data of K1 on `guide` (the image K1 is guided by: the smoothed one when K0 ran).  avg_in: the first-pass
+    average an implementation used (float32 [H,W], NaN = no weight); None = the float32 restatement's own."""
+    depth, guide = _f32(depth), _u8(guide)
+    h, w = depth.shape
+    tab = spatial_table(window, spatial_sigma)
+    st = Stage((h, w))
+    a = None if avg_in is None else _f32(avg_in)
+    assert a is None or a.shape == (h, w)
+    lib().okde_jbf_stage(w, h, _p(depth), _p(guide), _p(tab), window, C.c_float(color_sigma), C.c_float(depth_sigma),
+                         None if a is None else _p(a), st.ref())
+    return st
+
+
+def ers_stage(refined_depth, bgr, refined_labels, window=7, spatial_sigma=30.0, color_sigma=50.0, depth_sigma=70.0,
+              avg_in=None, dev_in=None) -> Stage:
+    """Stage data of K10 (inputs = the K9 result).  avg_in / dev_in: the pass-1 average and pass-2 deviation an
+    implementation used; None = the float32 restatement's own."""
+    rd, bgr, rl = _f32(refined_depth), _u8(bgr), _i32(refined_labels)
+    h, w = rd.shape
+    tab = spatial_table(window, spatial_sigma)
+    st = Stage((h, w), with_dev=True)
+    assert (avg_in is None) == (dev_in is None)
+    a = None if avg_in is None else _f32(avg_in)
+    d = None if dev_in is None else _f32(dev_in)
+    lib().okde_ers_stage(w, h, _p(rd), _p(bgr), _p(rl), _p(tab), window, C.c_float(color_sigma), C.c_float(depth_sigma),
+                         None if a is None else _p(a), None if d is None else _p(d), st.ref())
+    return st
+
+
+def stage_check(final, st: Stage, rtol=1e-4):
+    """The stage-wise parity bar, every pixel checked (st was evaluated at the implementation's own average / deviation):
+      (i)   that average (and deviation) against binary64 within the float32 first-order bound of kde_oracle.c;
+      (ii)  every pixel with no tap on a Q1 decision at that average: identical zero / NaN mask and <= rtol against the
+            binary64 last pass evaluated from it;
+      (iii) BAND pixels: inside [lo, hi] (both outcomes of the open decision at the same average), or 0 / NaN where admitted.
+    -> dict with the boolean map `bad` and the statistics the tests print."""
+    got = np.asarray(final, np.float32).reshape(st.shape)
+    g64 = got.astype(np.float64)
+    fl = st.flags
+    band = (fl & Stage.BAND) != 0
+    noweight = (fl & Stage.NOWEIGHT) != 0
+    mismatch = (fl & Stage.MISMATCH) != 0
+    nan_got = np.isnan(got)
+    nan_ref = np.isnan(st.fin64)
+    have_avg = ~noweight & ~np.isnan(st.avg32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        # (i) pass 1
+        cmp_avg = have_avg & np.isfinite(st.avg_tol) & (st.avg64 != 0)
+        avg_err = np.where(cmp_avg, np.abs(st.avg32.astype(np.float64) - st.avg64) / np.abs(st.avg64), 0.0)
+        avg_frac = np.where(cmp_avg, avg_err / st.avg_tol, 0.0)
+        bad_avg = cmp_avg & ~(avg_err <= st.avg_tol)
+        bad_dev = np.zeros(st.shape, bool)
+        dev_frac = np.zeros(st.shape)
+        if st.dev64 is not None:
+            cmp_dev = have_avg
+            d32 = st.dev32.astype(np.float64)
+            exact0 = cmp_dev & (st.dev64 == 0)
+            bad_dev = (exact0 & (d32 != 0)) | (cmp_dev & ~exact0 & ~(np.abs(d32 - st.dev64) <= st.dev_tol * st.dev64))
+            dev_frac = np.where(cmp_dev & ~exact0, np.abs(d32 - st.dev64) / (st.dev_tol * st.dev64), 0.0)
+        # (ii) strict pixels against the binary64 last pass at the given average
+        strict = ~band & ~mismatch
+        bad_nan = strict & (nan_ref != nan_got)
+        bad_zero = strict & ~nan_ref & ~nan_got & ((st.fin64 == 0) != (got == 0))
+        rel = np.where((st.fin64 != 0) & ~nan_ref & ~nan_got, np.abs(g64 - st.fin64) / np.abs(st.fin64), 0.0)
+        bad_rel = strict & (rel > rtol)
+        # (iii) BAND pixels against the interval
+        zero_ok = (fl & Stage.ZERO_OK) != 0
+        nan_ok = (fl & Stage.NAN_OK) != 0
+        inside = (st.hi > 0) & (g64 >= st.lo * (1 - rtol)) & (g64 <= st.hi * (1 + rtol))
+        ok_band = np.where(nan_got, nan_ok, np.where(got == 0, zero_ok, inside))
+        bad_band = band & ~mismatch & ~ok_band
+        width = np.where(band & (st.hi > 0), (st.hi - st.lo) / np.maximum(np.abs(st.fin64), 1e-300), 0.0)
+    bad = mismatch | bad_avg | bad_dev | bad_nan | bad_zero | bad_rel | bad_band
+    nb = int(band.sum())
+    q = lambda a, m, pc: float(np.percentile(a[m], pc)) if m.any() else 0.0
+    return {"bad": bad, "rel": rel, "n": int(got.size), "band": nb, "grid": int(((fl & Stage.GRID) != 0).sum()),
+            "band_frac": nb / max(1, got.size), "mismatch": int(mismatch.sum()),
+            "bad_avg": int(bad_avg.sum()), "bad_dev": int(bad_dev.sum()), "bad_nan": int(bad_nan.sum()),
+            "bad_zero": int(bad_zero.sum()), "bad_rel": int(bad_rel.sum()), "outside_band": int(bad_band.sum()),
+            "max_rel_strict": float(rel[strict].max()) if strict.any() else 0.0,
+            "avg_checked": int(cmp_avg.sum()),
+            "avg_bound_frac_p50": q(avg_frac, cmp_avg, 50), "avg_bound_frac_p99": q(avg_frac, cmp_avg, 99),
+            "avg_bound_frac_max": float(avg_frac.max()) if cmp_avg.any() else 0.0,
+            "avg_tol_p50": q(st.avg_tol, cmp_avg, 50), "avg_tol_p99": q(st.avg_tol, cmp_avg, 99),
+            "avg_tol_max": float(st.avg_tol[cmp_avg].max()) if cmp_avg.any() else 0.0,
+            "dev_bound_frac_max": float(dev_frac.max()),
+            "band_width_p50": q(width, band, 50), "band_width_p99": q(width, band, 99),
+            "band_width_max": float(width.max()) if nb else 0.0}
+
+
 def set_threads(n: int) -> int:
     return lib().okde_set_threads(int(n))
 
