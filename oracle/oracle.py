@@ -208,7 +208,7 @@ def stage_check(final, st: Stage, rtol=1e-4):
     have_avg = ~noweight & ~np.isnan(st.avg32)
     with np.errstate(invalid="ignore", divide="ignore"):
         # (i) pass 1
-        cmp_avg = have_avg & np.isfinite(st.avg_tol) & (st.avg64 != 0)
+        cmp_avg = have_avg & np.isfinite(st.avg_tol) & (st.avg64 != 0) & np.isfinite(st.avg64) & np.isfinite(st.avg32)
         avg_err = np.where(cmp_avg, np.abs(st.avg32.astype(np.float64) - st.avg64) / np.abs(st.avg64), 0.0)
         avg_frac = np.where(cmp_avg, avg_err / st.avg_tol, 0.0)
         bad_avg = cmp_avg & ~(avg_err <= st.avg_tol)

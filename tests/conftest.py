@@ -66,7 +66,7 @@ PARITY_LOG = []     # one line per assert_depth_close call with an envelope; pri
 
 def pytest_terminal_summary(terminalreporter):
     if PARITY_LOG:
-        terminalreporter.write_sep("-", "parity classes (no pixel is excluded; flagged pixels are held to the oracle's envelope)")
+        terminalreporter.write_sep("-", "parity classes (no pixel is excluded; [stage-wise] lines: BAND pixels are the only ones held to an interval)")
         for line in PARITY_LOG:
             terminalreporter.write_line(line)
 
@@ -100,6 +100,63 @@ def assert_depth_close(got, ref, rtol=1e-4, ill=None, max_bad=0, what="depth", m
         raise AssertionError(f"{what}: {nbad} pixels off (nan {r['bad_nan']}, zero-mask {r['bad_zero']}, rel {r['bad_rel']} "
                              f"max {r['max_rel_unflagged']:.3e}, outside envelope {r['outside_envelope']}); first: {detail}")
     return r["max_rel_unflagged"]
+
+
+def _stage_report(r, what, band_max, ignore=None):
+    PARITY_LOG.append(f"{what} [stage-wise]: {r['n']} px, BAND {r['band']} ({r['band_frac']:.2e}, grid {r['grid']}; width p50 "
+                      f"{r['band_width_p50']:.1e} p99 {r['band_width_p99']:.1e} max {r['band_width_max']:.1e}), strict max rel "
+                      f"{r['max_rel_strict']:.2e}, average within {r['avg_bound_frac_max']:.2f} of its bound "
+                      f"(bound p50 {r['avg_tol_p50']:.1e} max {r['avg_tol_max']:.1e}), deviation within {r['dev_bound_frac_max']:.2f}")
+    bad = r["bad"] if ignore is None else (r["bad"] & ~ignore)
+    nbad = int(bad.sum())
+    if nbad:
+        idx = [tuple(int(v) for v in i) for i in np.argwhere(bad)[:8]]
+        raise AssertionError(f"{what}: {nbad} pixels fail the stage-wise check (avg {r['bad_avg']}, dev {r['bad_dev']}, nan "
+                             f"{r['bad_nan']}, zero-mask {r['bad_zero']}, rel {r['bad_rel']} max {r['max_rel_strict']:.3e}, outside "
+                             f"band interval {r['outside_band']}, mismatch {r['mismatch']}); first: {idx}")
+    assert r["band_frac"] <= band_max, f"{what}: {r['band_frac']:.3e} of the pixels are BAND (> {band_max})"
+
+
+def assert_k1_stagewise(params, depth, guide, got, variant=-1, what="K1", band_max=0.05, rtol=1e-4, ignore=None):
+    """The K1 bar (round 3).  `got` is the PRODUCT library's output for (depth, guide, params, variant), [H,W]:
+      1. the same call on tools/hooks/libkde_hip_stage.so (same sources + dumps) must reproduce `got` to the bit, so the
+         first-pass average it dumps is the one the product kernel used;
+      2. that average against the binary64 average within the float32 first-order bound (oracle avg_bound);
+      3. every pixel with no tap on a Q1 decision AT THAT AVERAGE: <= rtol against pass 2 evaluated in binary64 from it,
+         identical zero mask; the few BAND pixels: inside the interval of both outcomes of the open decision.
+    `guide` is the image K1 is guided by (the K0 output when Process ran).  Returns the statistics."""
+    import ctypes
+    from kinectdepthmapenhancement_amd._native import JbfParams
+    from oracle import oracle as O
+    from tools.hooks import stage
+    p = JbfParams()
+    ctypes.memmove(ctypes.byref(p), ctypes.byref(params), ctypes.sizeof(JbfParams))
+    p.presmooth = 0
+    depth = np.ascontiguousarray(depth, np.float32)
+    guide = np.ascontiguousarray(guide, np.uint8)
+    out, avg, _ = stage.jbf_stage_run(p, depth[None], guide[None], variant)
+    same = stage.bits_equal(out[0], got) if ignore is None else stage.bits_equal(np.where(ignore, 0, out[0]), np.where(ignore, 0, got))
+    assert same, f"{what}: the stage build's output differs from the product library's"
+    st = O.jbf_stage(depth, guide, p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma, avg_in=avg[0])
+    r = O.stage_check(got, st, rtol)
+    _stage_report(r, what, band_max, ignore)
+    return r
+
+
+def assert_k10_stagewise(color_labels, depth_labels, depth, bgr, got, variant=0, what="K10", band_max=0.05, rtol=1e-4,
+                         ignore=None):
+    """The K10 bar (round 3), as assert_k1_stagewise: EdgeRefinedSuperpixel::EdgeRefining is re-run on the stage build
+    (final depth bit-identical to `got`), which dumps the label-restricted average and the mean absolute deviation per
+    pixel; both are checked against binary64, and the last pass is evaluated in binary64 from them."""
+    from oracle import oracle as O
+    from tools.hooks import stage
+    s = stage.ers_stage_run(color_labels, depth_labels, depth, bgr, variant)
+    eq = stage.bits_equal(s["depth"], got) if ignore is None else stage.bits_equal(np.where(ignore, 0, s["depth"]), np.where(ignore, 0, got))
+    assert eq, f"{what}: the stage build's output differs from the product library's"
+    st = O.ers_stage(s["edge_depth"], bgr, s["labels"], avg_in=s["avg"], dev_in=s["dev"])
+    r = O.stage_check(got, st, rtol)
+    _stage_report(r, what, band_max, ignore)
+    return r
 
 
 def assert_mrf_close(got, ref, what="MRF", rtol=1e-4):

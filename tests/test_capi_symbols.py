@@ -49,6 +49,21 @@ def test_hooks_are_not_part_of_the_product_abi(native):
     assert {n for n in exported if n.startswith("kde_")} == set(declared_functions())
 
 
+def test_stage_build_is_the_same_abi_plus_one_hook(native):
+    """tools/hooks/libkde_hip_stage.so = the product sources with -DKDE_STAGE_HOOKS: every product symbol plus
+    kde_stage_set (include/kde_test_hooks.h), which the product library must not contain"""
+    path = os.path.join(ROOT, "tools", "hooks", "libkde_hip_stage.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", os.path.dirname(path), "-s", "-j8", "libkde_hip_stage.so"])
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("kde_")}
+    assert exported == set(declared_functions()) | {"kde_stage_set"}
+    hooks_header = open(os.path.join(ROOT, "include", "kde_test_hooks.h")).read()
+    assert "kde_stage_set" in hooks_header and "kde_stage_set" not in open(HEADER).read()
+    prod = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True).stdout
+    assert "kde_stage_set" not in prod and "g_stage" not in prod
+
+
 def test_python_binding_covers_the_header(native):
     names = set(declared_functions())
     assert names == set(native.SIGNATURES), (names ^ set(native.SIGNATURES))

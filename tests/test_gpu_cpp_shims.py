@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, assert_depth_close, assert_mrf_close
+from conftest import ROOT, assert_depth_close, assert_k1_stagewise, assert_k10_stagewise, assert_mrf_close
 
 pytestmark = pytest.mark.gpu
 
@@ -31,12 +31,12 @@ def test_main_replay_matches_oracle(torch_cuda, oracle, synth, color_fixture, tm
     def load(name):
         return np.fromfile(prefix + name + ".f32", np.float32).reshape(480, 640)
 
-    jbf_ref, _, ill = oracle.jbf_process(depth, color_fixture, return_all=True)
-    assert_depth_close(load("jbf"), jbf_ref, 1e-4, ill=ill, what="C++ JBF")
+    jbf_ref, smooth, ill = oracle.jbf_process(depth, color_fixture, return_all=True)
+    from kinectdepthmapenhancement_amd import filters as F
+    assert_k1_stagewise(F.JointBilateralFilter.default_params(), depth, smooth, load("jbf"), what="C++ JBF", band_max=0.003)
     assert_mrf_close(load("mrf"), oracle.mrf_kernel(depth, color_fixture), "C++ MRF")
-    with oracle.ers_flags((480, 640)) as rill:
-        rg = oracle.rgbf_process(depth, oracle.p2r_depth(depth, K), color_fixture, 15, 20, K)
-    assert_depth_close(load("rgbf"), rg["refined_depth"], 1e-4, ill=rill, what="C++ RGBF")
+    rg = oracle.rgbf_process(depth, oracle.p2r_depth(depth, K), color_fixture, 15, 20, K)
+    assert_k10_stagewise(rg["sp_labels"], rg["dasp_labels"], depth, color_fixture, load("rgbf"), what="C++ RGBF", band_max=0.003)
     # the reference's only quality metric (main.cpp:220-308): mean 3-D error vs the averaged-depth cloud
     for name, d in (("input", depth), ("jbf", jbf_ref), ("rgbf", rg["refined_depth"])):
         e, n = oracle.mean_3d_error(oracle.p2r_depth(d, K), tpts)

@@ -4,12 +4,14 @@ config 2: one 640x480 frame, JointBilateralFilter::Process, radius 5 -> window 1
 config 3: 1920x1080, radius 9 -> window 19 (the pass north_star's roofline target names)
 config 4: one rank's shard of the 512-frame batch: 64 x 640x480 through the batched entry point
 config 5: DimensionConvertor -> JointBilateralFilter -> RegionGrowingBilateralFilter on one 1080p frame
-No pixel is excluded (conftest.assert_depth_close): unflagged pixels 1e-4 against the float32 restatement, flagged
-ones inside the oracle's binary64 envelope; u8 images and labels bit-exact."""
+No pixel is excluded.  K1 / K10 depth is checked stage by stage (conftest.assert_k1_stagewise / assert_k10_stagewise): the
+GPU's own first-pass average against binary64 within its float32 bound, the final value at 1e-4 against the last pass
+evaluated in binary64 from that average; pixels with a tap on a Q1 decision at that average (BAND) must be <= 0.3 % of
+the frame and are held to the interval of both outcomes.  u8 images and labels bit-exact."""
 import numpy as np
 import pytest
 
-from conftest import assert_depth_close
+from conftest import assert_depth_close, assert_k1_stagewise, assert_k10_stagewise
 from gpu_util import dev, host, pts_as_f32
 
 pytestmark = pytest.mark.gpu
@@ -37,18 +39,18 @@ def test_config2_vga_process_window11(torch_cuda, F, oracle, color_fixture, synt
     ref, smooth, env = oracle.jbf_process(depth, color_fixture, BENCH["window"], BENCH["ss"], BENCH["cs"], BENCH["ds"],
                                           return_all=True)
     assert np.array_equal(host(jbf.getSmoothImage_Device()), smooth)
-    assert_depth_close(host(jbf.getFiltered_Device()), ref, 1e-4, ill=env, what="config 2 (640x480, window 11)",
-                       max_flagged=0.05)
+    got = host(jbf.getFiltered_Device())
+    assert_k1_stagewise(jbf.params, depth, smooth, got, what="config 2 (640x480, window 11)", band_max=0.003)
+    assert_depth_close(got, ref, 1e-4, ill=env, what="config 2 vs the float32 restatement (cross-check)", max_flagged=0.05)
 
 
 def test_config3_fhd_process_window19(torch_cuda, F, oracle, synth):
     bgr, depth = synth.make_frame(3, 1920, 1080)
     jbf = F.JointBilateralFilter(1920, 1080, _params(F, 19, 3.0, 7.65, 20.0))
     jbf.Process(dev(torch_cuda, depth), dev(torch_cuda, bgr))
-    ref, smooth, env = oracle.jbf_process(depth, bgr, 19, 3.0, 7.65, 20.0, return_all=True)
+    smooth = oracle.cv_bilateral(bgr, 5, 30.0, 30.0)
     assert np.array_equal(host(jbf.getSmoothImage_Device()), smooth)            # K0 u8 image at 1080p: bit-exact
-    assert_depth_close(host(jbf.getFiltered_Device()), ref, 1e-4, ill=env, what="config 3 (1920x1080, window 19)",
-                       max_flagged=0.05)
+    assert_k1_stagewise(jbf.params, depth, smooth, host(jbf.getFiltered_Device()), what="config 3 (1920x1080, window 19)", band_max=0.003)
 
 
 def test_config4_one_ranks_shard_64_vga_frames(torch_cuda, F, oracle, synth):
@@ -59,10 +61,8 @@ def test_config4_one_ranks_shard_64_vga_frames(torch_cuda, F, oracle, synth):
     out = host(jbf.process_batch(dev(torch_cuda, depth), dev(torch_cuda, bgr)))
     smooth = host(jbf.getSmoothImage_Device(n))
     for f in (0, 31, 63):
-        ref, sm, env = oracle.jbf_process(depth[f], bgr[f], BENCH["window"], BENCH["ss"], BENCH["cs"], BENCH["ds"],
-                                          return_all=True)
-        assert np.array_equal(smooth[f], sm)
-        assert_depth_close(out[f], ref, 1e-4, ill=env, what=f"config 4 shard frame {f}", max_flagged=0.05)
+        assert np.array_equal(smooth[f], oracle.cv_bilateral(bgr[f], 5, 30.0, 30.0))
+        assert_k1_stagewise(jbf.params, depth[f], smooth[f], out[f], what=f"config 4 shard frame {f}", band_max=0.003)
     # frames are independent units: a frame filtered alone is bit-identical to the same frame inside the batch
     single = F.JointBilateralFilter(640, 480, _params(F, **BENCH))
     single.Process(dev(torch_cuda, depth[17]), dev(torch_cuda, bgr[17]))
@@ -89,15 +89,14 @@ def test_config5_fhd_chain_against_the_oracle(torch_cuda, F, oracle, synth):
     conv.projectiveToReal(filt, pts)
     rg.Process(filt, pts, color)
     got_filt = host(filt)
-    ref_filt, smooth, env = oracle.jbf_process(depth, bgr, return_all=True)
+    smooth = oracle.cv_bilateral(bgr, 5, 30.0, 30.0)
     assert np.array_equal(host(jbf.getSmoothImage_Device()), smooth)
-    assert_depth_close(got_filt, ref_filt, 1e-4, ill=env, what="config 5 JBF (1080p)", max_flagged=0.05)
+    assert_k1_stagewise(jbf.params, depth, smooth, got_filt, what="config 5 JBF (1080p)", band_max=0.003)
     opts = oracle.p2r_depth(got_filt, K)
     assert np.array_equal(host(pts), pts_as_f32(opts))
-    with oracle.ers_flags((h, w)) as env2:
-        ref = oracle.rgbf_process(got_filt, opts, bgr, 15, 20, K)
+    ref = oracle.rgbf_process(got_filt, opts, bgr, 15, 20, K)
     assert np.array_equal(host(rg.getSPLabels_Device()), ref["sp_labels"])
     assert np.array_equal(host(rg.getDASPLabels_Device()), ref["dasp_labels"])
     assert np.array_equal(host(rg.getRefinedLabels_Device()), ref["refined_labels"])
-    assert_depth_close(host(rg.getRefinedDepth_Device()), ref["refined_depth"], 1e-4, ill=env2,
-                       what="config 5 RGBF (1080p)", max_flagged=0.05)
+    assert_k10_stagewise(ref["sp_labels"], ref["dasp_labels"], got_filt, bgr, host(rg.getRefinedDepth_Device()),
+                         what="config 5 RGBF (1080p)", band_max=0.003)

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, assert_depth_close, assert_mrf_close
+from conftest import GOLDEN, assert_depth_close, assert_k1_stagewise, assert_k10_stagewise, assert_mrf_close
 from oracle.oracle import Env
 from gpu_util import dev, host
 
@@ -27,6 +27,8 @@ def test_golden_crops(torch_cuda, synth):
     out = t.empty((1, 48, 64), dtype=t.float32, device="cuda")
     j2.filter_batch(dev(t, cd[None]), dev(t, cb[None]), out)
     assert_depth_close(host(out)[0], g["k1_jbf_w11_s3_c7p65"], 1e-4, ill=Env.from_dict(g, "k1_jbf_w11_s3_c7p65"), what="golden w11", max_flagged=0.05)
+    assert_k1_stagewise(p, cd, cb, host(out)[0], what="golden w11")
+    assert_k1_stagewise(jbf.params, cd, g["k0_smooth"], host(jbf.getFiltered_Device()), what="golden Process")
     conv = F.DimensionConvertor(); conv.setCameraParameters(Kc, 64, 48)
     pts = t.empty((48, 64, 3), dtype=t.float32, device="cuda")
     conv.projectiveToReal(dev(t, cd), pts)
@@ -37,6 +39,7 @@ def test_golden_crops(torch_cuda, synth):
     assert np.array_equal(host(rg.getDASPLabels_Device()), g["k7_dasp_labels"])
     assert np.array_equal(host(rg.getRefinedLabels_Device()), g["rgbf_refined_labels"])
     assert_depth_close(host(rg.getRefinedDepth_Device()), g["rgbf_refined_depth"], 1e-4, ill=Env.from_dict(g, "rgbf_refined_depth"), what="golden RGBF")
+    assert_k10_stagewise(g["k7_sp_labels"], g["k7_dasp_labels"], cd, cb, host(rg.getRefinedDepth_Device()), what="golden RGBF")
     mrf = F.MarkovRandomField(64, 48)
     mrf.Process(dev(t, cd), dev(t, cb))
     assert_mrf_close(host(mrf.getFiltered_Device()), g["mrf"], "golden MRF")

@@ -1,0 +1,97 @@
+"""The stage-wise parity machinery itself, on the CPU: the float32 restatement's OWN evaluation must pass the check the
+GPU kernels are held to (oracle.stage_check on okde_jbf_stage / okde_ers_stage, kde_oracle.h okde_stage) -- its first-pass
+average within the float32 first-order bound of the binary64 one, its final value within 1e-4 of the last pass evaluated
+in binary64 from that average -- and the check must reject perturbed averages / finals."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("cfg", [(5, 70.0, 50.0, 20.0), (11, 3.0, 7.65, 20.0), (19, 3.0, 7.65, 20.0), (7, 5.0, 20.0, 4.0),
+                                 (3, 1.0, 0.0, 20.0), (5, 70.0, 50.0, 0.0)])
+def test_k1_restatement_passes_its_own_stage_check(oracle, frame, cfg):
+    bgr, depth = frame(2, 160, 120)
+    w, ss, cs, ds = cfg
+    out = oracle.jbf_kernel(depth, bgr, w, ss, cs, ds)
+    st = oracle.jbf_stage(depth, bgr, w, ss, cs, ds)                   # avg_in=None: the restatement's own average
+    r = oracle.stage_check(out, st)
+    assert not r["bad"].any(), {k: v for k, v in r.items() if k not in ("bad", "rel")}
+    assert r["mismatch"] == 0 and r["max_rel_strict"] < 2e-5 and r["avg_bound_frac_max"] < 1.0
+    assert r["band_frac"] < 0.02
+    # the check has teeth: an average moved by 30 of its bounds, or a final value moved by 3e-4, is rejected
+    avg = st.avg32.copy()
+    ok = np.isfinite(avg) & np.isfinite(st.avg_tol)
+    avg[ok] = (avg[ok].astype(np.float64) * (1.0 + 30.0 * st.avg_tol[ok])).astype(np.float32)
+    r2 = oracle.stage_check(out, oracle.jbf_stage(depth, bgr, w, ss, cs, ds, avg_in=avg))
+    assert r2["bad_avg"] > 0.9 * ok.sum()
+    r3 = oracle.stage_check(out * np.float32(1.0003), st)
+    assert r3["bad_rel"] > 0.9 * (out != 0).sum() - r["band"]
+
+
+def test_k1_stage_flags_band_pixels_and_brackets_both_outcomes(oracle):
+    """a tap exactly on the depth-factor underflow distance (288.41 mm at sigma_d 20): BAND, and [lo, hi] holds the value
+    with the tap skipped (full weight S*cf) and with it kept (weight ~1e-45)"""
+    h, w = 9, 9
+    depth = np.full((h, w), 1000.0, np.float32)
+    bgr = np.full((h, w, 3), 50, np.uint8)
+    st0 = oracle.jbf_stage(depth, bgr, 5, 70.0, 50.0, 20.0)
+    assert not st0.band.any()
+    avg = float(st0.avg32[4, 4])
+    depth[4, 5] = np.float32(avg + 288.4100)                           # inside the 1.5e-4 band around sqrt(150 ln2 * 800)
+    st = oracle.jbf_stage(depth, bgr, 5, 70.0, 50.0, 20.0, avg_in=np.full((h, w), avg, np.float32))
+    assert st.band[4, 4]
+    assert st.hi[4, 4] > st.lo[4, 4] * 1.001                            # skipped vs kept differ by about 288 / 25
+    far = depth.copy()
+    far[4, 5] = np.float32(avg + 295.0)                                 # clearly beyond: skipped, no band
+    st2 = oracle.jbf_stage(far, bgr, 5, 70.0, 50.0, 20.0, avg_in=np.full((h, w), avg, np.float32))
+    assert not st2.band[4, 4] and abs(st2.fin64[4, 4] - st.hi[4, 4]) < 0.5
+
+
+def test_k1_stage_reports_a_missing_or_spurious_average(oracle, frame):
+    bgr, depth = frame(3, 64, 48)
+    st = oracle.jbf_stage(depth, bgr)
+    avg = st.avg32.copy()
+    avg[10, 10] = np.nan                                                # weights exist but the implementation claims none
+    r = oracle.stage_check(oracle.jbf_kernel(depth, bgr), oracle.jbf_stage(depth, bgr, avg_in=avg))
+    assert r["mismatch"] == 1 and r["bad"][10, 10]
+    none = np.zeros_like(depth)                                         # no valid depth anywhere: NOWEIGHT, average must be NaN
+    st0 = oracle.jbf_stage(none, bgr)
+    assert ((st0.flags & oracle.Stage.NOWEIGHT) != 0).all() and np.isnan(st0.avg32).all()
+    assert not oracle.stage_check(np.zeros_like(depth), st0)["bad"].any()
+    assert oracle.stage_check(np.ones_like(depth), st0)["bad"].all()
+
+
+@pytest.mark.parametrize("case", ["synthetic", "flat-nan-quirk", "speckle"])
+def test_k10_restatement_passes_its_own_stage_check(oracle, synth, frame, case):
+    if case == "synthetic":
+        bgr, depth = frame(12, 160, 120)
+        K = synth.intrinsics(160, 120)
+        pts = oracle.p2r_depth(depth, K)
+        sp = oracle.dasp_segmentation(bgr, pts, 5, 6, K, 200.0, 40.0, 0.0, 1)[0]
+        da = oracle.dasp_segmentation(bgr, pts, 5, 6, K, 100.0, 20.0, 200.0, 1)[0]
+        rl, rd9 = oracle.ers_edge_refining(sp, da, depth)
+    elif case == "flat-nan-quirk":
+        rd9 = np.full((24, 40), 1024.0, np.float32)
+        rd9[5:9, 7:30] = 0
+        bgr = np.full((24, 40, 3), 9, np.uint8)
+        rl = np.zeros((24, 40), np.int32)
+    else:
+        rng = np.random.default_rng(17)
+        H, W = 51, 97
+        rl = ((np.arange(W)[None, :] + 2) // 7 + 13 * ((np.arange(H)[:, None] + 3) // 5)).astype(np.int32)
+        rd9 = (800 + 40 * rl + rng.normal(0, 30, (H, W))).astype(np.float32)
+        rd9[rng.random((H, W)) < 0.25] = 0
+        bgr = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        bgr[:, 40:60] = 77
+    out = oracle.ers_enhance(rd9, bgr, rl)
+    st = oracle.ers_stage(rd9, bgr, rl)
+    r = oracle.stage_check(out, st)
+    assert not r["bad"].any(), {k: v for k, v in r.items() if k not in ("bad", "rel")}
+    assert r["max_rel_strict"] < 2e-5 and r["avg_bound_frac_max"] < 1.0 and r["dev_bound_frac_max"] < 1.0
+    if case == "flat-nan-quirk":
+        assert np.isnan(out).sum() > 0 and np.array_equal(np.isnan(out), np.isnan(st.fin64))
+        # the NaN class follows the deviation: with a deviation of one rounding error instead of exactly 0 there is no 0/0
+        dev = st.dev32.copy()
+        dev[np.isnan(out)] = 1e-4
+        st2 = oracle.ers_stage(rd9, bgr, rl, avg_in=st.avg32, dev_in=dev)
+        assert not np.isnan(st2.fin64[np.isnan(out)]).any()
+        assert oracle.stage_check(out, st2)["bad_dev"] >= np.isnan(out).sum()      # ... and that deviation is rejected

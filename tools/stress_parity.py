@@ -21,7 +21,7 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
     """-> number of violations"""
     a = argparse.Namespace(cases=cases, seed=seed, dump=dump, ers=ers or only == "ers", only=only)
     import torch
-    from conftest import assert_depth_close, assert_mrf_close
+    from conftest import assert_depth_close, assert_k1_stagewise, assert_k10_stagewise, assert_mrf_close
     from gpu_util import dev, host
     from kinectdepthmapenhancement_amd import KdeError, filters as F, synth
     from oracle import oracle as O
@@ -75,6 +75,7 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
                         raise
                     state["got"] = host(out)[0].copy()
                     state["variant"] = np.array([v])
+                    assert_k1_stagewise(p, depth, bgr, state["got"], variant=v, what=f"K1 v{v} win {win} sig {ss}/{cs}/{ds}", band_max=1.0)
                     assert_depth_close(state["got"], ref, 1e-4, ill=ill, what=f"K1 v{v} win {win} sig {ss}/{cs}/{ds}")
                 desc = f"k1 {w}x{h} win {win} sig {ss}/{cs}/{ds} variants {len(cands)}"
             elif kind == "k0":
@@ -231,6 +232,7 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
                     assert np.array_equal(host(ers.getRefinedLabels_Device()), el), f"ERS v{v} refined labels"
                     assert np.array_equal(host(ers.getEdgeStageDepth_Device()), ed), f"ERS v{v} depth after edge_refining"
                     state["got"] = host(ers.getRefinedDepth_Device()).copy()
+                    assert_k10_stagewise(cl, dl, depth, bgr, state["got"], variant=v, what=f"ERS v{v} refined depth", band_max=1.0)
                     assert_depth_close(state["got"], rd, 1e-4, ill=ill, what=f"ERS v{v} refined depth")
                 desc = f"ers {w}x{h} regions {k} jitter {jit:.1f}"
             elif kind == "spdsr":
@@ -251,6 +253,9 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
                     rl, rd, _ = O.spdsr_head(depth, pts, bgr, rows, cols, K)
                 assert np.array_equal(host(sr.getRefinedLabels_Device()), rl), "SPDSR labels"
                 got = host(sr.getRefinedDepth_Device())
+                sp_l = O.dasp_segmentation(bgr, pts, rows, cols, K, 200.0, 10.0, 0.0, 5)[0]
+                da_l = O.dasp_segmentation(bgr, pts, rows, cols, K, 0.0, 10.0, 200.0, 5)[0]
+                assert_k10_stagewise(sp_l, da_l, depth, bgr, got, what="SPDSR head depth", band_max=1.0)
                 assert_depth_close(got, rd, 1e-4, ill=ill, what="SPDSR head depth")
                 gpts = host(sr.getEdgeEnhanced3DPoints_Device())
                 gp = np.ascontiguousarray(gpts).view(O.FLOAT3).reshape(h, w)
@@ -291,6 +296,7 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
                 state.update(bgr=bgr, depth=depth, ref=ref["refined_depth"], labels=ref["refined_labels"], **ill.to_dict("env"),
                              params=np.array([rows, cols]), got=host(rg.getRefinedDepth_Device()).copy(),
                              stage=host(rg.getEdgeStageDepth_Device()).copy() if hasattr(rg, "getEdgeStageDepth_Device") else np.zeros(1))
+                assert_k10_stagewise(ref["sp_labels"], ref["dasp_labels"], depth, bgr, state["got"], what=f"RGBF depth grid {rows}x{cols}", band_max=1.0)
                 assert_depth_close(state["got"], ref["refined_depth"], 1e-4, ill=ill, what=f"RGBF depth grid {rows}x{cols}")
                 desc = f"rgbf {w}x{h} grid {rows}x{cols}"
             print(f"[{case}] ok   {desc}", flush=True)
@@ -304,8 +310,17 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
     if PARITY_LOG:
         import re
         fl = [float(m.group(1)) for m in (re.search(r"flagged \d+ \(([0-9.e+-]+):", ln) for ln in PARITY_LOG) if m]
-        print(f"stress: flagged-pixel fraction over {len(fl)} depth comparisons: median {np.median(fl):.2e}, max {max(fl):.2e} "
-              f"(all held to the oracle's envelope; none excluded)")
+        if fl:
+            print(f"stress: [float32 restatement cross-check] flagged-pixel fraction over {len(fl)} depth comparisons: median "
+                  f"{np.median(fl):.2e}, max {max(fl):.2e} (held to the oracle's envelope)")
+        st = [ln for ln in PARITY_LOG if "[stage-wise]" in ln]
+        bf = [float(m.group(1)) for m in (re.search(r"BAND \d+ \(([0-9.e+-]+),", ln) for ln in st) if m]
+        mr = [float(m.group(1)) for m in (re.search(r"strict max rel ([0-9.e+-]+),", ln) for ln in st) if m]
+        af = [float(m.group(1)) for m in (re.search(r"average within ([0-9.]+) of", ln) for ln in st) if m]
+        if bf:
+            print(f"stress: [stage-wise] {len(bf)} depth comparisons: BAND fraction median {np.median(bf):.2e} p99 {np.percentile(bf, 99):.2e} "
+                  f"max {max(bf):.2e}; strict-pixel max rel err median {np.median(mr):.2e} max {max(mr):.2e}; average within "
+                  f"{max(af):.2f} of its float32 bound at worst")
     print(f"stress: {a.cases} cases, {bad} violations")
     return bad
 
