@@ -461,23 +461,30 @@ static float jbf_pass1_f32(int width, int height, const float* depth, const uint
     return weight > 0.0f ? w_average / weight : NAN;
 }
 
-/* Relative bound on |avg32 - avg64| for a faithful float32 evaluation of sum(d f) / sum(f) over weights w[] (use[]
- * selects taps): recursive summation over the taps that can round the sums ((n - 1) / 2 ulps, see n_significant),
- * products and the division (4 ulps), PLUS the weights' own float32 noise: a weight exp(-x) S formed in float32 is off
- * by up to about (32 + 2 x) 2^-24 relative (x rounded before the exponential: x 2^-24; the exponential: 2 ulps; the
- * product with S; in the log2-domain kernels the rounding of the argument log2 S + 24 - x log2 e, its table entry and
- * the scale of x), and that noise is not common to the taps: it moves the average by sum f e |d - avg| / sum f. */
+/* Relative first-order bound on |avg32 - avg64| for a faithful float32 evaluation of A / W, A = sum(d f), W = sum(f), over
+ * the weights w[] (use[] selects taps), in u = 2^-24:
+ *   - recursive summation: adding tap k to a running sum is off by at most u of the partial sum -- and by no more than the
+ *     tap itself, which is what happens to a tap lighter than half an ulp of the sum (it is absorbed).  The two sums round
+ *     independently, so tap k costs min(w_k / W, u) + min(d_k w_k / A, u): a rim tap of a 19 x 19 window at sigma_s = 0.5
+ *     that lies beyond a depth step can be absorbed by W and still round A by a whole ulp (found by
+ *     tools/stress_parity.py: 336 taps, 5 heavier than half an ulp of W, the float32 restatement's own average 3e-6 off);
+ *     the products d f, the division and the conversion of the result: 6 u;
+ *   - the weights' own float32 noise: a weight exp(-x) S formed in float32 is off by up to about (32 + 2 x) u relative (x
+ *     rounded before the exponential: x u; the exponential: 2 ulps; the product with S; in the log2-domain kernels the
+ *     rounding of the argument log2 S + 24 - x log2 e, of its table entry and of the scale of x), and that noise is not
+ *     common to the taps: it moves the average by sum f e |d - avg| / W. */
 static double avg_bound(const double* d, const double* w, const uint8_t* use, int n, double under, double wt, double avg)
 {
     const double u = 0x1p-24;
-    double noise = 0.0;
+    const double at = fabs(avg) * wt;
+    double noise = 0.0, sum = 0.0;
     for (int k = 0; k < n; k++) {
         if ((use && !use[k]) || !(w[k] > under)) continue;
         const double xk = w[k] < 1.0 ? -log(w[k]) : 0.0;
         noise += w[k] * (32.0 + 2.0 * xk) * u * fabs(d[k] - avg);
+        sum += fmin(w[k] / wt, u) + (at > 0.0 ? fmin(fabs(d[k]) * w[k] / at, u) : u);
     }
-    const double nsig = n_significant(w, use, n, wt, under);
-    return (4.0 + 0.5 * nsig) * 2.0 * u + (avg != 0.0 ? noise / (wt * fabs(avg)) : 0.0);
+    return sum + 6.0 * u + (at > 0.0 ? noise / at : 0.0);
 }
 
 void okde_jbf_stage(int width, int height, const float* depth, const uint8_t* guide, const float* spatial,
