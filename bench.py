@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the joint-bilateral hot path on MI355X (BASELINE.json's metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: this process only spawns the N ranks, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one JointBilateralFilter::Process (K0 colour pre-smoothing + K1 joint bilateral filter)
@@ -20,14 +20,21 @@ One JSON line is printed by rank 0; besides the contract fields it carries
                  profile of exactly this code (profiles/pmc_bench.json, matched by a hash of the kernel sources)
                  and the launch time measured live; and `fhd_w19`: the same figures for the pass north_star's
                  roofline target names (32 x 1920x1080, window 19; BASELINE config 3);
-  verified     — frame 0 of the TIMED output compared with the CPU oracle after the timed region (every pixel:
-                 1e-4 or inside the oracle's envelope, oracle.parity_check);
+  verified     — frame 0 of the TIMED output checked after the timed region, stage by stage (oracle.stage_check): the
+                 stage build of the library (tools/hooks/libkde_hip_stage.so: same sources + dumps) must reproduce it to
+                 the bit, its first-pass average is held to the float32 first-order bound of the binary64 average, and
+                 the final value to 1e-4 against pass 2 evaluated in binary64 FROM that average; K0's u8 image exact;
   cpu_baseline — the CPU oracle (a scalar port of the CUDA kernels; the reference has no CPU path)
-                 timed on this host on a bounded sample of the same workload.
+                 timed on this host on a bounded sample of the same workload (OpenMP over rows), and
+  cpu_baseline_1t — the same on one thread (SURVEY 8d);
+  from_idle    — the same W + K steps measured first, from an idle GPU (no wake-up load): what the fixed W = 5 / K = 20
+                 contract gives by itself; `value` is the steady-clock figure measured right after.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -66,7 +73,42 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the 1080p / reference-constant side measurements")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_bench.json"))
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed output")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend of the N > 1 path (nccl = RCCL)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank uses cuda:0 (rehearsal of the N > 1 path on a one-GPU box; needs --backend gloo)")
+    ap.add_argument("--first-frame", type=int, default=0, help="global index of the first frame (N = 1 runs of one shard of a larger batch)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="everything but the GPU work: launch, process group, parameter broadcast, partition, reductions (CPU test of the N > 1 path)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: spawn the N ranks ourselves -- one process per GPU, started
+    BEFORE anything touches a GPU (this parent never imports torch.cuda), with the environment torch.distributed.run
+    would give them -- relay rank 0's single JSON line and return the worst exit code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    # a rank that dies leaves the others waiting in a collective: give them a grace period, then end them (exact PIDs)
+    failed_at = None
+    while any(q.poll() is None for q in procs):
+        if failed_at is None and any(q.poll() not in (None, 0) for q in procs):
+            failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 30.0:
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+        time.sleep(0.1)
+    out0 = procs[0].stdout.read().decode(errors="replace")
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return max(abs(q.returncode) for q in procs)
 
 
 def pmc_lookup(path, window):
@@ -112,19 +154,47 @@ def k1_roofline(px_per_launch, k1_ms, entry, src):
     return r
 
 
-def verify_frame0(args, p, synth, first_seed, out0, smooth0):
-    """frame 0 of the timed output against the CPU oracle (the checker; never part of the timed path)"""
+def verify_frame0(args, p, synth, first_seed, out0, smooth0, variant):
+    """frame 0 of the timed output, checked after the timed region (the checkers are never part of the timed path):
+    K0 bytes against the oracle; K1 stage by stage -- tools/hooks/libkde_hip_stage.so (the product sources + dumps) must
+    reproduce the timed output to the bit, its first-pass average is compared with binary64 within the float32 bound, and
+    the final value with pass 2 evaluated in binary64 from that average (oracle.stage_check).  The float32 restatement
+    with its envelope (round 2's bar) is reported next to it as a cross-check."""
+    import ctypes
     from oracle import oracle as O
+    from tools.hooks import stage
     O.build()
     O.set_threads(usable_cores())
     bgr, depth = synth.make_frame(first_seed, args.width, args.height)
     ref, sm, env = O.jbf_process(depth, bgr, p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma, return_all=True)
-    chk = O.parity_check(out0, ref, env, 1e-4)
     k0_exact = bool(np.array_equal(smooth0, sm))
-    return {"ok": bool(k0_exact and not chk["bad"].any()), "frame": 0, "k0_u8_exact": k0_exact,
-            "max_rel_err_unflagged": chk["max_rel_unflagged"], "pixels": chk["n"], "flagged": chk["flagged"],
-            "max_rel_err_flagged_vs_f32": chk["max_rel_flagged"], "outside_envelope": chk["outside_envelope"],
-            "bar": "1e-4 relative + identical zero mask on unflagged pixels; flagged pixels inside the oracle's binary64 envelope"}
+    q = type(p)()
+    ctypes.memmove(ctypes.byref(q), ctypes.byref(p), ctypes.sizeof(q))
+    q.presmooth = 0
+    sout, savg, _ = stage.jbf_stage_run(q, depth[None], sm[None], variant)
+    same = bool(stage.bits_equal(sout[0], out0))
+    st = O.jbf_stage(depth, sm, p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma, avg_in=savg[0])
+    r = O.stage_check(out0, st, 1e-4)
+    chk = O.parity_check(out0, ref, env, 1e-4)
+    fl = env.flagged
+    with np.errstate(invalid="ignore", divide="ignore"):
+        width = np.where(fl & (env.hi > 0), (env.hi - env.lo) / np.maximum(np.abs(ref.astype(np.float64)), 1e-300), 0.0)
+    return {"ok": bool(k0_exact and same and not r["bad"].any() and not chk["bad"].any()), "frame": 0, "pixels": r["n"],
+            "k0_u8_exact": k0_exact, "stage_build_bit_identical": same,
+            "stagewise": {"bad": int(r["bad"].sum()), "band_pixels": r["band"], "band_frac": r["band_frac"],
+                          "max_rel_err_strict": r["max_rel_strict"], "avg_checked": r["avg_checked"],
+                          "avg_err_over_bound_p50_p99_max": [r["avg_bound_frac_p50"], r["avg_bound_frac_p99"], r["avg_bound_frac_max"]],
+                          "avg_bound_rel_p50_max": [r["avg_tol_p50"], r["avg_tol_max"]],
+                          "band_width_p50_p99_max": [r["band_width_p50"], r["band_width_p99"], r["band_width_max"]]},
+            "float32_restatement_crosscheck": {"bad": int(chk["bad"].sum()), "flagged": chk["flagged"], "flagged_band": chk["band"],
+                                               "flagged_cond": chk["cond"], "max_rel_err_unflagged": chk["max_rel_unflagged"],
+                                               "max_rel_err_flagged_vs_f32": chk["max_rel_flagged"],
+                                               "envelope_width_p50": float(np.percentile(width[fl], 50)) if fl.any() else 0.0,
+                                               "envelope_width_p99": float(np.percentile(width[fl], 99)) if fl.any() else 0.0,
+                                               "envelope_width_max": float(width.max()) if fl.any() else 0.0},
+            "bar": "K0 bytes exact; stage build == timed output to the bit; first-pass average within its float32 first-order bound "
+                   "of the binary64 average; every pixel with no tap on a Q1 decision at that average: identical zero mask and <= 1e-4 "
+                   "against pass 2 evaluated in binary64 from it; BAND pixels inside the interval of both outcomes"}
 
 
 def make_inputs(synth, torch, first_seed, n, w, h, distinct):
@@ -193,65 +263,93 @@ def usable_cores():
     return min(n, int(os.environ.get("KDE_CPU_THREADS", "16")))
 
 
-def cpu_baseline(args, synth, seconds):
+def cpu_baseline(args, synth, seconds, threads=None):
     from oracle import oracle as O
     O.build()
-    cores = usable_cores()
+    cores = usable_cores() if threads is None else threads
     O.set_threads(cores)
-    bgr, depth = synth.make_frame(0, args.width, args.height)
-    O.jbf_process(depth, bgr, args.window, args.spatial_sigma, args.color_sigma, args.depth_sigma)   # warm-up
+    frames = [synth.make_frame(s, args.width, args.height) for s in range(4)]       # distinct frames, cycled
+    O.jbf_process(frames[0][1], frames[0][0], args.window, args.spatial_sigma, args.color_sigma, args.depth_sigma)   # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
+        bgr, depth = frames[n % len(frames)]
         O.jbf_process(depth, bgr, args.window, args.spatial_sigma, args.color_sigma, args.depth_sigma)
         n += 1
         el = time.perf_counter() - t0
         if el >= seconds and n >= 2:
             break
     return {"value": n * args.width * args.height / el / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": f"{n} x ({args.width}x{args.height}) frames of the same Process (K0+K1, window {args.window}) "
-                      f"through oracle/kde_oracle.c, OpenMP over rows, {el:.1f} s"}
+            "sample": f"{n} x ({args.width}x{args.height}) frames (4 distinct, cycled) of the same Process (K0+K1, window {args.window}) "
+                      f"through oracle/kde_oracle.c, " + (f"OpenMP over rows on {cores} threads" if cores > 1 else "one thread") + f", {el:.1f} s"}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))            # the parent never touches a GPU
     # RCCL prints its version banner / warnings on the C-level stdout: keep the real stdout for the ONE JSON
     # line of the contract and send everything else that writes to fd 1 to stderr
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
     import torch
     import torch.distributed as dist
-    from kinectdepthmapenhancement_amd import filters, sharding, synth
+    from kinectdepthmapenhancement_amd import sharding, synth
+    from kinectdepthmapenhancement_amd._native import JbfParams
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"WORLD_SIZE={world} != --gpus {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also for N = 1: same code path)
+    if args.share_device and args.backend == "nccl" and world > 1:
+        raise SystemExit("--share-device needs --backend gloo (RCCL wants one device per rank)")
+    use_dist = "RANK" in os.environ          # launched by torch.distributed.run or by launch_ranks (also for N = 1)
+    if not args.dry_run:
+        torch.cuda.set_device(local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        if args.backend == "nccl" and not args.dry_run:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
     barrier = dist.barrier if use_dist else (lambda: None)
 
     # ---- parameter block: rank 0 decides, everyone receives the same bytes --------------------------
-    p = filters.JointBilateralFilter.default_params()
-    p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma = args.window, args.spatial_sigma, args.color_sigma, args.depth_sigma
-    probe = filters.JointBilateralFilter(8, 8, p)
-    blk = sharding.pack_params(p, table=probe.spatial_table()) if rank == 0 else np.zeros(sharding.BLOCK_LEN)
+    if args.dry_run:
+        p = JbfParams(args.window, args.spatial_sigma, args.color_sigma, args.depth_sigma, 1, 5, 30.0, 30.0)
+        r = args.window // 2
+        yy, xx = np.mgrid[-r:r + 1, -r:r + 1]
+        host_table = lambda q: np.exp(-(xx * xx + yy * yy) / (2.0 * q.spatial_sigma ** 2)).astype(np.float32)
+    else:
+        from kinectdepthmapenhancement_amd import filters
+        p = filters.JointBilateralFilter.default_params()
+        p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma = args.window, args.spatial_sigma, args.color_sigma, args.depth_sigma
+        host_table = lambda q: filters.JointBilateralFilter(8, 8, q).spatial_table()
+    blk = sharding.pack_params(p, table=host_table(p)) if rank == 0 else np.zeros(sharding.BLOCK_LEN)
     blk = sharding.broadcast_params(blk)
     p, _, _, _, table0 = sharding.unpack_params(blk)
     replicas_only = False
-    if not np.array_equal(filters.JointBilateralFilter(8, 8, p).spatial_table(), table0):
+    if not np.array_equal(host_table(p), table0):
         replicas_only = True        # would mean ranks disagree on the host-computed table: flag the run
 
     # ---- this rank's shard of the global batch ------------------------------------------------------
     total_frames = args.frames_per_gpu * world
     first, count = sharding.partition(total_frames, world)[rank]
+    first += args.first_frame
     W, H = args.width, args.height
+    if args.dry_run:
+        barrier()
+        dt = sharding.allreduce_max(1e-3 * (rank + 1))
+        checksum = sharding.allreduce_sum([float(first), float(count)])
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "dry_run": True, "max_dt_over_ranks": dt, "replicas_only": replicas_only,
+                              "checksum": {"sum_first_frames": checksum[0], "frames": int(checksum[1])},
+                              "config": {"window": p.window_size, "frames_per_gpu": count}}), file=real_stdout, flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
     color, depth = make_inputs(synth, torch, first, count, W, H, args.distinct_frames)
     smooth = torch.empty_like(color)
     out = torch.empty_like(depth)
@@ -259,6 +357,14 @@ def main():
     if args.variant >= 0:
         jbf.set_variant(args.variant)
 
+    # from an idle GPU first (the W + K contract by itself), then at the clock the GPU holds under load (the headline)
+    idle = None
+    if args.wakeup_ms > 0:
+        dt_i, _, k1_i, _ = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, 0.0)
+        dt_i = sharding.allreduce_max(dt_i)
+        idle = {"value": total_frames * W * H * args.steps / dt_i / 1e6, "ms_per_step": dt_i / args.steps * 1e3,
+                "k1_launch_ms_first_median_last": [float(k1_i[0]), float(np.median(k1_i)), float(k1_i[-1])],
+                "note": "same W warm-up + K timed steps started from an idle GPU (lowest clock level), measured before the headline"}
     dt, k0_ms, k1_ms, woke = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, args.wakeup_ms)
     dt = sharding.allreduce_max(dt)
     checksum = sharding.allreduce_sum([float(out.double().sum().item()), float(count)])
@@ -267,11 +373,14 @@ def main():
         px_per_launch = count * W * H
         k1_avg_ms = float(np.mean(k1_ms))
         entry, src = pmc_lookup(args.pmc_json, p.window_size)
-        roof = {"bound": "hbm", "limiter": "valu-issue (K1 does 2 exp + ~30 flops per tap against 11 B/pixel; see roofline.valu)",
+        roof = {"bound": "hbm", "bound_measured": "valu-issue",
+                "limiter": "valu-issue (K1 does 2 exp + ~30 flops per tap against 11 B/pixel; see roofline.valu)",
                 "kernel": "K1 joint_bilateral_filtering"}
         roof.update(k1_roofline(px_per_launch, k1_avg_ms, entry, src))
         roof["k0_avg_launch_ms"] = float(np.mean(k0_ms))
         roof["launch_ms_first_min_max"] = [float(k1_ms[0]), float(np.min(k1_ms)), float(np.max(k1_ms))]   # clock ramp shows here
+        roof["launch_ms"] = {"mean": k1_avg_ms, "median": float(np.median(k1_ms)), "min": float(np.min(k1_ms)),
+                             "max": float(np.max(k1_ms)), "first": float(k1_ms[0])}
         res = {
             "metric": METRIC,
             "value": total_frames * W * H * args.steps / dt / 1e6,
@@ -285,16 +394,20 @@ def main():
                             f"synthetic RGB-D frames ({count} per GPU), window {p.window_size} (radius {p.window_size // 2}), "
                             f"sigma_s {p.spatial_sigma:g} px, sigma_r {p.color_sigma:g}/255, sigma_d {p.depth_sigma:g} mm",
                 "frames_per_gpu": count, "width": W, "height": H, "window": p.window_size,
-                "sharding": f"contiguous frame blocks x{world}, params broadcast from rank 0" + (" [REPLICAS ONLY]" if replicas_only else ""),
+                "sharding": f"contiguous frame blocks x{world}, params broadcast from rank 0 ({args.backend if use_dist else 'single process'}"
+                            + (", all ranks on cuda:0" if args.share_device else "") + ")" + (" [REPLICAS ONLY]" if replicas_only else ""),
                 "kernel_variant": filters.JointBilateralFilter.variants()[args.variant] if args.variant >= 0 else "auto",
             },
             "roofline": roof,
             "checksum": {"sum_filtered_mm": checksum[0], "frames": int(checksum[1])},
         }
+        if idle:
+            res["from_idle"] = idle
         if not args.no_verify:
-            res["verified"] = verify_frame0(args, p, synth, first, out[0].cpu().numpy(), smooth[0].cpu().numpy())
+            res["verified"] = verify_frame0(args, p, synth, first, out[0].cpu().numpy(), smooth[0].cpu().numpy(), args.variant)
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(args, synth, args.cpu_seconds)
+            res["cpu_baseline_1t"] = cpu_baseline(args, synth, max(3.0, args.cpu_seconds / 2), threads=1)
         if world == 1 and not args.no_extra:
             res["also"] = side_measurements(torch, filters, synth, args)
             res["roofline"]["fhd_w19"] = res["also"].pop("fhd_w19_config3")
@@ -330,6 +443,46 @@ def side_measurements(torch, filters, synth, args):
     # BASELINE config 3 as SURVEY 8(d) sizes it: 32 frames = 730 MB of algorithmic traffic, beyond the 256 MB Infinity Cache
     run("fhd_w19_config3", 1920, 1080, 32, 2, 19, 3.0, 7.65, 20.0)
     run("vga_reference_constants_w5", 640, 480, 64, 8, 5, 70.0, 50.0, 20.0)
+    # ---- the headline's dependence on content (tile-level rule elision fires on smooth tiles only): K1 alone on the
+    # synthetic frames and on the reference's own colour frame (input/color.jpg decode, textured) tiled to the batch,
+    # each with the default kernel and with its "-noelide" twin (every tile runs the full-rule body: the floor)
+    try:
+        from PIL import Image
+        fix = np.ascontiguousarray(np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "color_640x480.png")).convert("RGB"))[..., ::-1])
+    except Exception:
+        fix = None
+    names = filters.JointBilateralFilter.variants()
+    p11 = filters.JointBilateralFilter.default_params()
+    p11.window_size, p11.spatial_sigma, p11.color_sigma, p11.depth_sigma, p11.presmooth = 11, 3.0, 7.65, 20.0, 0
+    n64 = 64
+    syn_c, syn_d = make_inputs(synth, torch, 0, n64, 640, 480, 8)
+    content = {"synthetic": syn_c}
+    if fix is not None:
+        content["reference_colour_frame_x64"] = torch.from_numpy(fix).cuda()[None].repeat(n64, 1, 1, 1).contiguous()
+    res11 = torch.empty_like(syn_d)
+    legs = {}
+    for cname, col in content.items():
+        for vname in ("auto", "w11-pk2-16x16-false-v1-noelide"):
+            if vname != "auto" and vname not in names:
+                continue
+            j = filters.JointBilateralFilter(640, 480, p11, max_batch=n64)
+            if vname != "auto":
+                j.set_variant(names.index(vname))
+            for _ in range(3):
+                j.filter_batch(syn_d, col, res11)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+            for a_, b_ in evs:
+                a_.record()
+                j.filter_batch(syn_d, col, res11)
+                b_.record()
+            torch.cuda.synchronize()
+            ms = float(np.median([a_.elapsed_time(b_) for a_, b_ in evs]))
+            legs[f"{cname}/{'default' if vname == 'auto' else 'noelide'}"] = {"k1_ms": ms, "k1_mpix_s": n64 * 640 * 480 / ms / 1e3}
+            j.close()
+    out["k1_w11_content_dependence"] = {"workload": "K1 alone (guide = the colour frames themselves), 64 x 640x480, window 11, sigma 3/7.65/20, "
+                                                    "median of 10 launches", **legs}
+    del content, syn_c, syn_d, res11
+
     # empirical HBM ceiling: float4 copy of 1 GiB (read + write)
     n = 1 << 28
     a = torch.empty(n, dtype=torch.float32, device="cuda").normal_()

@@ -267,7 +267,7 @@ __device__ __forceinline__ f2 pk_mul_clamp(f2 a, f2 b)
 
 // second launch bound = waves per SIMD the register allocator must leave room for: the four rule-specialised bodies
 // below share one kernel, and without it the window-19 instance grew from 131 to 182 VGPRs (3 -> 2 waves per SIMD)
-template <int WIN, int NP, int BX, int BY, bool CACHE, bool CSKIP, bool VL>
+template <int WIN, int NP, int BX, int BY, bool CACHE, bool CSKIP, bool VL, bool ELIDE_ON = true>
 __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
 {
     constexpr int R = WIN / 2;
@@ -316,7 +316,9 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     // Positive floats order like their bit patterns, so everything is reduced as uint32.
     // (Only for windows >= 9: at windows 5 and 7 a thread has 25 / 49 units of work and the statistics cost more than
     //  the elided instructions return -- measured 33.9 vs 28.8 us on one 1080p frame at window 5.)
-    constexpr bool ELIDE = WIN >= 9;
+    // ELIDE_ON = false ("-noelide" variants): the same kernel without the statistics and with the full-rule body everywhere --
+    // the data-independent floor of the window, measured next to the default by bench.py
+    constexpr bool ELIDE = WIN >= 9 && ELIDE_ON;
     __shared__ uint32_t s_stat[8];           // dmin, dmax, (min, max) of b, g, r
     if (ELIDE) {
         if (tid < 8) s_stat[tid] = (tid == 0 || (tid >= 2 && !(tid & 1))) ? 0xffffffffu : 0u;
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     }
 }
 
-template <int WIN, int NP, int BX, int BY, bool CACHE, bool VL>
+template <int WIN, int NP, int BX, int BY, bool CACHE, bool VL, bool ELIDE_ON = true>
 int launch_pk_variant(const JbfLaunch& l, const FastArgs& fa, bool cskip, hipStream_t s)
 {
     FastArgs a = fa;
@@ -631,9 +633,9 @@ int launch_pk_variant(const JbfLaunch& l, const FastArgs& fa, bool cskip, hipStr
     a.div_tx = make_fastdiv24((uint32_t)a.tiles_x, (uint64_t)a.tiles_x * a.tiles_y);
     if (blocks > 0x7fffffffLL) return fail(KDE_ERR_INVALID, "jbf: batch too large for one launch");
     if (cskip)
-        hipLaunchKernelGGL((jbf_pk_kernel<WIN, NP, BX, BY, CACHE, true, VL>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
+        hipLaunchKernelGGL((jbf_pk_kernel<WIN, NP, BX, BY, CACHE, true, VL, ELIDE_ON>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
     else
-        hipLaunchKernelGGL((jbf_pk_kernel<WIN, NP, BX, BY, CACHE, false, VL>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
+        hipLaunchKernelGGL((jbf_pk_kernel<WIN, NP, BX, BY, CACHE, false, VL, ELIDE_ON>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }
@@ -670,6 +672,8 @@ struct Variant {
     {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v4", WIN, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, true>}
 #define KS(WIN, NP, BX, BY, CACHE) \
     {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v1", WIN, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, false>}
+#define KN(WIN, NP, BX, BY, CACHE) \
+    {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v1-noelide", WIN, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, false, false>}
 const Variant kVariants[] = {
     // the FIRST variant listed for a window is the built-in choice (interleaved A/B sweep on MI355X,
     // profiles/r02_sweep_k1_variants.log); the others stay selectable for the tile sweep of BASELINE config 3
@@ -680,12 +684,15 @@ const Variant kVariants[] = {
     // and the scalar kernels at 2 and 1 pixels per thread (32x16, 32x8)
     KS(11, 2, 16, 16, false), K(11, 2, 16, 16, false), KS(11, 1, 16, 16, false), K(11, 1, 16, 16, false), K(11, 1, 32, 8, false),
     KS(11, 1, 32, 8, false), KS(11, 2, 32, 8, false), V(11, 2, 16, 16, false), V(11, 1, 32, 8, false),
+    KN(11, 2, 16, 16, false),      // the default without tile-level rule elision: the window's data-independent floor
     KS(19, 1, 16, 16, false), KS(19, 2, 16, 16, false), K(19, 2, 16, 16, false), K(19, 1, 16, 16, false), K(19, 1, 32, 8, false),
     KS(19, 1, 32, 8, false), KS(19, 2, 32, 8, false), V(19, 2, 16, 16, false), V(19, 1, 32, 8, false),
+    KN(19, 1, 16, 16, false),
 };
 #undef V
 #undef K
 #undef KS
+#undef KN
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 }  // namespace

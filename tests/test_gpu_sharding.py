@@ -54,3 +54,25 @@ def test_cpp_shard_replay_with_rccl_broadcast(torch_cuda):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["verified"] is True and line["tables_match_rank0"] is True
     assert line["params_broadcast"].startswith("rccl") and line["devices"] >= 1 and line["frames"] == 6
+
+
+def test_bench_py_launches_two_ranks_itself_and_equals_two_single_runs(torch_cuda):
+    """`python bench.py --gpus 2` (no launcher) spawns its two ranks; on this one-GPU box both use cuda:0 over a gloo group.
+    128 frames, and the checksum of the filtered output equals the sum of the two shards run as N = 1 jobs."""
+    bench = os.path.join(ROOT, "bench.py")
+    common = ["--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-extra", "--no-verify", "--wakeup-ms", "0"]
+
+    def run(extra):
+        r = subprocess.run([sys.executable, bench] + extra + common, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0])
+
+    two = run(["--gpus", "2", "--backend", "gloo", "--share-device"])
+    a = run(["--gpus", "1", "--first-frame", "0"])
+    b = run(["--gpus", "1", "--first-frame", "64"])
+    assert two["n_gpus"] == 2 and two["checksum"]["frames"] == 128 and two["config"]["frames_per_gpu"] == 64
+    assert two["checksum"]["sum_filtered_mm"] == a["checksum"]["sum_filtered_mm"] + b["checksum"]["sum_filtered_mm"]
+    assert a["checksum"]["sum_filtered_mm"] != b["checksum"]["sum_filtered_mm"]
+    assert two["value"] > 0 and two["scaling"] == "weak"
