@@ -83,6 +83,16 @@ inline void intrinsic_to_array(const double* K, double out[9])
 
 static_assert(sizeof(float3) == sizeof(kde_float3), "float3 must be 12 bytes packed");
 
+// every class takes a colour image as "continuous CV_8UC3 of the object's size" (cv::gpu::createContinuous,
+// JointBilateralFilter.cpp:13, main.cpp:62): a padded or wrongly sized GpuMat is rejected, not silently misread
+template <class GpuMatLike>
+inline void require_continuous_8uc3(const GpuMatLike& img, int width, int height, const char* who)
+{
+    if (img.rows != height || img.cols != width || static_cast<size_t>(img.step) != static_cast<size_t>(width) * 3)
+        throw Error(KDE_ERR_INVALID, std::string(who) + ": colour image must be a continuous " + std::to_string(width) + "x" +
+                                         std::to_string(height) + " 8UC3 (step == 3 * width)");
+}
+
 namespace ref {
 
 // ------------------------------------------------------------------------------------------------
@@ -162,6 +172,12 @@ public:
         float* p = nullptr;
         check(kde_mrf_filtered_device(h_, &p));
         return p;
+    }
+    float* getFiltered_Host() const      // MarkovRandomField.h:16
+    {
+        const float* p = nullptr;
+        check(kde_mrf_filtered_host(h_, stream_, &p));
+        return const_cast<float*>(p);
     }
     void setStream(void* hip_stream) { stream_ = hip_stream; }
 
@@ -256,7 +272,7 @@ class DepthAdaptiveSuperpixel {
 public:
     typedef kde_superpixel superpixel;             // SuperpixelSegmentation.h:17-24
     typedef kde_label_distance label_distance;     // :26-29
-    DepthAdaptiveSuperpixel(int width, int height) { check(kde_dasp_create(&h_, width, height)); }
+    DepthAdaptiveSuperpixel(int width, int height) : Width(width), Height(height) { check(kde_dasp_create(&h_, width, height)); }
     virtual ~DepthAdaptiveSuperpixel() { kde_dasp_destroy(h_); }
     DepthAdaptiveSuperpixel(const DepthAdaptiveSuperpixel&) = delete;
     DepthAdaptiveSuperpixel& operator=(const DepthAdaptiveSuperpixel&) = delete;
@@ -272,6 +288,7 @@ public:
     void Segmentation(const GpuMatLike& color_image, float3* points3d_device, float color_sigma,
                       float spatial_sigma, float depth_sigma, int iteration)
     {
+        require_continuous_8uc3(color_image, Width, Height, "DepthAdaptiveSuperpixel::Segmentation");
         check(kde_dasp_segmentation(h_, color_image.data, reinterpret_cast<const kde_float3*>(points3d_device),
                                     color_sigma, spatial_sigma, depth_sigma, iteration, stream_));
     }
@@ -290,6 +307,7 @@ public:
     void setStream(void* hip_stream) { stream_ = hip_stream; }
 
 private:
+    int Width, Height;
     kde_dasp* h_ = nullptr;
     void* stream_ = nullptr;
 };
@@ -297,7 +315,7 @@ private:
 // ------------------------------------------------------------------------------------------------
 class EdgeRefinedSuperpixel {
 public:
-    EdgeRefinedSuperpixel(int width, int height) { check(kde_ers_create(&h_, width, height)); }
+    EdgeRefinedSuperpixel(int width, int height) : Width(width), Height(height) { check(kde_ers_create(&h_, width, height)); }
     ~EdgeRefinedSuperpixel() { kde_ers_destroy(h_); }
     EdgeRefinedSuperpixel(const EdgeRefinedSuperpixel&) = delete;
     EdgeRefinedSuperpixel& operator=(const EdgeRefinedSuperpixel&) = delete;
@@ -305,6 +323,7 @@ public:
     template <class GpuMatLike>
     void EdgeRefining(int* color_label_device, int* depth_label_device, float* depth_device, const GpuMatLike& color_image)
     {
+        require_continuous_8uc3(color_image, Width, Height, "EdgeRefinedSuperpixel::EdgeRefining");
         check(kde_ers_edge_refining(h_, color_label_device, depth_label_device, depth_device, color_image.data, stream_));
     }
     int* getRefinedLabels_Device()
@@ -334,6 +353,7 @@ public:
     void setStream(void* hip_stream) { stream_ = hip_stream; }
 
 private:
+    int Width, Height;
     kde_ers* h_ = nullptr;
     void* stream_ = nullptr;
 };
@@ -341,7 +361,12 @@ private:
 // ------------------------------------------------------------------------------------------------
 class RegionGrowingBilateralFilter {
 public:
-    RegionGrowingBilateralFilter(int width, int height) { check(kde_rgbf_create(&h_, width, height)); }
+    RegionGrowingBilateralFilter(int width, int height) : Width(width), Height(height) { check(kde_rgbf_create(&h_, width, height)); }
+    // extension: buffers for max_batch independent frames per ProcessBatch (the reference processes one frame per call)
+    RegionGrowingBilateralFilter(int width, int height, int max_batch) : Width(width), Height(height)
+    {
+        check(kde_rgbf_create_batch(&h_, width, height, max_batch));
+    }
     ~RegionGrowingBilateralFilter() { kde_rgbf_destroy(h_); }
     RegionGrowingBilateralFilter(const RegionGrowingBilateralFilter&) = delete;
     RegionGrowingBilateralFilter& operator=(const RegionGrowingBilateralFilter&) = delete;
@@ -356,7 +381,13 @@ public:
     template <class GpuMatLike>
     void Process(float* depth_device, float3* points_device, const GpuMatLike& color_device)
     {
+        require_continuous_8uc3(color_device, Width, Height, "RegionGrowingBilateralFilter::Process");
         check(kde_rgbf_process(h_, depth_device, reinterpret_cast<const kde_float3*>(points_device), color_device.data, stream_));
+    }
+    // n frames back to back in every argument; the getters then return n frames back to back, each bit-identical to Process
+    void ProcessBatch(int n, const float* depth_device, const float3* points_device, const uint8_t* bgr_device)
+    {
+        check(kde_rgbf_process_batch(h_, n, depth_device, reinterpret_cast<const kde_float3*>(points_device), bgr_device, stream_));
     }
     float* getRefinedDepth_Device()
     {
@@ -379,6 +410,7 @@ public:
     void setStream(void* hip_stream) { stream_ = hip_stream; }
 
 private:
+    int Width, Height;
     kde_rgbf* h_ = nullptr;
     void* stream_ = nullptr;
 };
@@ -386,7 +418,11 @@ private:
 // ------------------------------------------------------------------------------------------------
 class SPDepthSuperResolution {
 public:
-    SPDepthSuperResolution(int width, int height) { check(kde_spdsr_create(&h_, width, height)); }
+    SPDepthSuperResolution(int width, int height) : Width(width), Height(height) { check(kde_spdsr_create(&h_, width, height)); }
+    SPDepthSuperResolution(int width, int height, int max_batch) : Width(width), Height(height)      // extension, as RGBF's
+    {
+        check(kde_spdsr_create_batch(&h_, width, height, max_batch));
+    }
     ~SPDepthSuperResolution() { kde_spdsr_destroy(h_); }
     SPDepthSuperResolution(const SPDepthSuperResolution&) = delete;
     SPDepthSuperResolution& operator=(const SPDepthSuperResolution&) = delete;
@@ -401,7 +437,12 @@ public:
     template <class GpuMatLike>
     void Process(float* depth_device, float3* points_device, const GpuMatLike& color_device)
     {
+        require_continuous_8uc3(color_device, Width, Height, "SPDepthSuperResolution::Process");
         check(kde_spdsr_process(h_, depth_device, reinterpret_cast<const kde_float3*>(points_device), color_device.data, stream_));
+    }
+    void ProcessBatch(int n, const float* depth_device, const float3* points_device, const uint8_t* bgr_device)
+    {
+        check(kde_spdsr_process_batch(h_, n, depth_device, reinterpret_cast<const kde_float3*>(points_device), bgr_device, stream_));
     }
     float* getRefinedDepth_Device()
     {
@@ -436,6 +477,7 @@ public:
     void setStream(void* hip_stream) { stream_ = hip_stream; }
 
 private:
+    int Width, Height;
     kde_spdsr* h_ = nullptr;
     void* stream_ = nullptr;
 };

@@ -19,6 +19,8 @@
  *     "valid" means depth > 50.0f everywhere (JointBilateralFilter.cu:21).
  *   - a handle is one stream-ordered context (scratch buffers are members, like the reference
  *     objects); handles are independent, a single handle is not thread-safe.
+ *   - a handle belongs to the device that was current when it was created (kde_set_device): calls
+ *     made while another device is current return KDE_ERR_INVALID instead of launching on it.
  *   - batched entry points take n independent frames laid out back to back
  *     (frame f at base + f * W*H elements) and are the unit that is sharded across GPUs.
  */
@@ -126,6 +128,10 @@ int kde_mrf_destroy(kde_mrf* h);
 /* void MarkovRandomField::Process(float* depth_device, cv::gpu::GpuMat color_image) (MarkovRandomField.cu:42-49) */
 int kde_mrf_process_batch(kde_mrf* h, int n, const float* depth_dev, const uint8_t* bgr_dev, float* filtered_dev, void* stream);
 int kde_mrf_filtered_device(kde_mrf* h, float** out);
+/* float* getFiltered_Host() (MarkovRandomField.h:16; refreshed after every Process in the reference,
+ * MarkovRandomField.cu:48): object-owned pinned memory, lazily copied from the object's own Filtered_Device here;
+ * synchronises the stream.  Holds the frames of the last call that wrote Filtered_Device. */
+int kde_mrf_filtered_host(kde_mrf* h, void* stream, const float** out);
 
 /* ============================================================================================
  * DimensionConvertor — DimensionConvertor/DimensionConvertor.{h,cpp,cu}
@@ -232,6 +238,14 @@ int kde_rgbf_set_parameters(kde_rgbf* h, int rows, int cols, const double* K9); 
  * SP->Segmentation(200,40,0,1); DASP->Segmentation(100,20,200,1); ERS->EdgeRefining(SP labels, DASP labels, ...) */
 int kde_rgbf_process(kde_rgbf* h, const float* depth_dev, const kde_float3* points_dev,
                      const uint8_t* bgr_dev, void* stream);
+/* A batch of independent frames (the unit north_star shards across GPUs; the reference has only the single-frame call):
+ * kde_rgbf_create_batch sizes the object's buffers for max_batch frames, kde_rgbf_process_batch runs Process on n <=
+ * max_batch frames laid out back to back -- every kernel of the chain takes the whole batch in one launch, and each
+ * frame's labels and refined depth are bit-identical to its single-frame kde_rgbf_process.  The getters then return
+ * n frames back to back (frame f at + f * W*H). */
+int kde_rgbf_create_batch(kde_rgbf** out, int width, int height, int max_batch);
+int kde_rgbf_process_batch(kde_rgbf* h, int n, const float* depth_dev, const kde_float3* points_dev,
+                           const uint8_t* bgr_dev, void* stream);
 int kde_rgbf_refined_depth_device(kde_rgbf* h, float** out);                       /* .cpp:39-41 */
 int kde_rgbf_refined_depth_host(kde_rgbf* h, void* stream, const float** out);     /* .cpp:42-44 */
 int kde_rgbf_refined_labels_device(kde_rgbf* h, int32_t** out);
@@ -250,6 +264,12 @@ int kde_spdsr_destroy(kde_spdsr* h);
 int kde_spdsr_set_parameters(kde_spdsr* h, int rows, int cols, const double* K9);
 int kde_spdsr_process(kde_spdsr* h, const float* depth_dev, const kde_float3* points_dev,
                       const uint8_t* bgr_dev, void* stream);
+/* batched form, as kde_rgbf_process_batch: head (labels, refined depth, edge-enhanced points) bit-identical per frame;
+ * the plane fit accumulates double-precision moments with atomics, so the tail agrees with the single-frame call to
+ * the same 1e-4 it agrees with itself from run to run.  ClusterND: n tables of rows*cols float4 back to back. */
+int kde_spdsr_create_batch(kde_spdsr** out, int width, int height, int max_batch);
+int kde_spdsr_process_batch(kde_spdsr* h, int n, const float* depth_dev, const kde_float3* points_dev,
+                            const uint8_t* bgr_dev, void* stream);
 int kde_spdsr_refined_depth_device(kde_spdsr* h, float** out);
 int kde_spdsr_refined_depth_host(kde_spdsr* h, void* stream, const float** out);
 int kde_spdsr_refined_labels_device(kde_spdsr* h, int32_t** out);

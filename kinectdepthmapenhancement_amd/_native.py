@@ -66,6 +66,7 @@ SIGNATURES = {
     "kde_mrf_destroy": (_i, [_vp]),
     "kde_mrf_process_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "kde_mrf_filtered_device": (_i, [_vp, _pp]),
+    "kde_mrf_filtered_host": (_i, [_vp, _vp, _pp]),
     "kde_dimconv_create": (_i, [_pp]),
     "kde_dimconv_destroy": (_i, [_vp]),
     "kde_dimconv_set_camera": (_i, [_vp, _vp, _i, _i]),
@@ -105,6 +106,8 @@ SIGNATURES = {
     "kde_rgbf_destroy": (_i, [_vp]),
     "kde_rgbf_set_parameters": (_i, [_vp, _i, _i, _vp]),
     "kde_rgbf_process": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "kde_rgbf_create_batch": (_i, [_pp, _i, _i, _i]),
+    "kde_rgbf_process_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "kde_rgbf_refined_depth_device": (_i, [_vp, _pp]),
     "kde_rgbf_refined_depth_host": (_i, [_vp, _vp, _pp]),
     "kde_rgbf_refined_labels_device": (_i, [_vp, _pp]),
@@ -114,6 +117,8 @@ SIGNATURES = {
     "kde_spdsr_destroy": (_i, [_vp]),
     "kde_spdsr_set_parameters": (_i, [_vp, _i, _i, _vp]),
     "kde_spdsr_process": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "kde_spdsr_create_batch": (_i, [_pp, _i, _i, _i]),
+    "kde_spdsr_process_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "kde_spdsr_refined_depth_device": (_i, [_vp, _pp]),
     "kde_spdsr_refined_depth_host": (_i, [_vp, _vp, _pp]),
     "kde_spdsr_refined_labels_device": (_i, [_vp, _pp]),

@@ -26,11 +26,20 @@ namespace {
 // of the terms into LDS, and wavefront 0 then adds them up in the reference's order: the kernel is a latency chain on a
 // nearly empty GPU (75 workgroups at 300 clusters), and this cuts the chain from 121 x (distance + sqrt) to 31 x that
 // plus 121 additions (11 -> 4 us at 1080p).  The square root's argument is an integer < 2^24: sqrt_int24 is sqrtf there.
+// A batch of frames (kde_rgbf_process_batch / kde_spdsr_process_batch): blockIdx.y = frame; every frame has its own
+// colour, cloud and cluster table, so a frame's result does not depend on what else is in the launch.
 __global__ __launch_bounds__(256) void sample_clusters_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
                                                              const kde_float3* __restrict__ pts,
                                                              kde_superpixel* __restrict__ mean,
                                                              kde_float3* __restrict__ centers)
 {
+    {
+        const size_t fpx = (size_t)blockIdx.y * g.width * g.height, fk = (size_t)blockIdx.y * g.rows * g.cols;
+        bgr += fpx * 3;
+        pts += fpx;
+        mean += fk;
+        centers += fk;
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane >> 4, tid = lane & 15;
     const int cluster = blockIdx.x * 4 + sub;
@@ -128,6 +137,7 @@ struct CalcSet {
 template <int NS>
 struct CalcSets {
     CalcSet s[NS];
+    int write_ld;      // 0: the (distance, label) records are not stored (a pipeline with ONE assignment step never reads them)
 };
 
 // FIRST = the assignment step that follows sampleInitialClusters: init_LD (K5) is folded in -- the previous
@@ -148,6 +158,18 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
     ClusterRec* recs = reinterpret_cast<ClusterRec*>(smem);
     const int nclusters = g.rows * g.cols;
     constexpr int NTAB = FIRST ? 1 : NS;
+    {   // blockIdx.z = frame of a batch: per-frame colour, cloud, cluster tables and outputs
+        const size_t fpx = (size_t)blockIdx.z * g.width * g.height, fk = (size_t)blockIdx.z * nclusters;
+        bgr += fpx * 3;
+        pts += fpx;
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            sets.s[n].ld += fpx;
+            sets.s[n].labels += fpx;
+            sets.s[n].mean += fk;
+            sets.s[n].centers += fk;
+        }
+    }
     if (USE_LDS) {
 #pragma unroll
         for (int n = 0; n < NTAB; n++)
@@ -280,7 +302,7 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
                 o.l = -1;
                 o.d = 0.0f;
             }
-            cs.ld[p] = o;
+            if (!FIRST || sets.write_ld) cs.ld[p] = o;
             cs.labels[p] = o.l;
         }
     };
@@ -330,15 +352,20 @@ struct AnalyzeSet {
 };
 struct AnalyzeSets {
     AnalyzeSet s[2];
+    int nsets;          // blockIdx.z = frame * nsets + segmenter
 };
 
 __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
                                                               const kde_float3* __restrict__ pts, AnalyzeSets sets,
                                                               const float* __restrict__ intr)
 {
-    const int32_t* __restrict__ labels = sets.s[blockIdx.z].labels;
-    kde_superpixel* __restrict__ mean = sets.s[blockIdx.z].mean;
-    kde_float3* __restrict__ centers = sets.s[blockIdx.z].centers;
+    const unsigned frame = blockIdx.z / (unsigned)sets.nsets, seg = blockIdx.z - frame * (unsigned)sets.nsets;
+    const size_t fpx = (size_t)frame * g.width * g.height, fk = (size_t)frame * g.rows * g.cols;
+    bgr += fpx * 3;
+    pts += fpx;
+    const int32_t* __restrict__ labels = sets.s[seg].labels + fpx;
+    kde_superpixel* __restrict__ mean = sets.s[seg].mean + fk;
+    kde_float3* __restrict__ centers = sets.s[seg].centers + fk;
     __shared__ int si[7][256];     // r g b x y size npoints
     __shared__ float sf[3][256];   // X Y Z
     const int tid = threadIdx.x;
@@ -493,10 +520,10 @@ __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const
 
 }  // namespace
 
-int launch_dasp_sample(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
+int launch_dasp_sample(const DaspGeom& g, int n, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
                        kde_float3* centers, hipStream_t s)
 {
-    hipLaunchKernelGGL(sample_clusters_kernel, dim3(ceil_div(g.rows * g.cols, 4)), dim3(256), 0, s, g, bgr, pts, mean,
+    hipLaunchKernelGGL(sample_clusters_kernel, dim3(ceil_div(g.rows * g.cols, 4), n), dim3(256), 0, s, g, bgr, pts, mean,
                        centers);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
@@ -516,8 +543,8 @@ static CalcSet make_set(const DaspGeom& g, kde_label_distance* ld, const kde_sup
 }
 
 template <int NS>
-static int launch_calc_sets(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const CalcSets<NS>& sets, bool first,
-                            hipStream_t s)
+static int launch_calc_sets(const DaspGeom& g, int n, const uint8_t* bgr, const kde_float3* pts, const CalcSets<NS>& sets,
+                            bool first, hipStream_t s)
 {
     const float half = (float)(g.wx + g.wy) / 2.0f;
     const float win2 = half * half;
@@ -525,7 +552,7 @@ static int launch_calc_sets(const DaspGeom& g, const uint8_t* bgr, const kde_flo
     const int tables = first ? 1 : NS;
     const bool lds = tables * nclusters <= kMaxLdsClusters;
     const size_t bytes = lds ? (size_t)tables * nclusters * sizeof(ClusterRec) : 0;
-    dim3 grid(ceil_div(g.width, 64), ceil_div(g.height, 4));
+    dim3 grid(ceil_div(g.width, 64), ceil_div(g.height, 4), n);
     CalcDivs dv;
     dv.wx = make_fastdiv24((uint32_t)g.wx, (uint64_t)g.width);
     dv.wy = make_fastdiv24((uint32_t)g.wy, (uint64_t)g.height);
@@ -548,19 +575,22 @@ int launch_dasp_calc_ld(const DaspGeom& g, const uint8_t* bgr, const kde_float3*
 {
     CalcSets<1> sets;
     sets.s[0] = make_set(g, ld, mean, centers, labels, color_sigma, spatial_sigma, depth_sigma);
-    return launch_calc_sets<1>(g, bgr, pts, sets, first, s);
+    sets.write_ld = 1;
+    return launch_calc_sets<1>(g, 1, bgr, pts, sets, first, s);
 }
 
 // both segmenters of a pipeline in one pass (see CalcSet); with first = true both read set A's sampled clusters
-int launch_dasp_calc_ld_dual(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld_a,
+int launch_dasp_calc_ld_dual(const DaspGeom& g, int n, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld_a,
                              const kde_superpixel* mean_a, const kde_float3* centers_a, int32_t* labels_a,
                              const float sig_a[3], kde_label_distance* ld_b, const kde_superpixel* mean_b,
-                             const kde_float3* centers_b, int32_t* labels_b, const float sig_b[3], bool first, hipStream_t s)
+                             const kde_float3* centers_b, int32_t* labels_b, const float sig_b[3], bool first, bool write_ld,
+                             hipStream_t s)
 {
     CalcSets<2> sets;
     sets.s[0] = make_set(g, ld_a, mean_a, centers_a, labels_a, sig_a[0], sig_a[1], sig_a[2]);
     sets.s[1] = make_set(g, ld_b, mean_b, centers_b, labels_b, sig_b[0], sig_b[1], sig_b[2]);
-    return launch_calc_sets<2>(g, bgr, pts, sets, first, s);
+    sets.write_ld = write_ld ? 1 : 0;
+    return launch_calc_sets<2>(g, n, bgr, pts, sets, first, s);
 }
 
 int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const int32_t* labels,
@@ -568,20 +598,22 @@ int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3*
 {
     AnalyzeSets sets;
     sets.s[0] = sets.s[1] = AnalyzeSet{labels, mean, centers};
+    sets.nsets = 1;
     hipLaunchKernelGGL(analyze_clusters_kernel, dim3(g.cols, g.rows, 1), dim3(256), 0, s, g, bgr, pts, sets, intr_dev);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }
 
 // both segmenters of a pipeline in one launch (same geometry, colour, cloud and intrinsics)
-int launch_dasp_analyze_dual(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const int32_t* labels_a,
+int launch_dasp_analyze_dual(const DaspGeom& g, int n, const uint8_t* bgr, const kde_float3* pts, const int32_t* labels_a,
                              kde_superpixel* mean_a, kde_float3* centers_a, const int32_t* labels_b, kde_superpixel* mean_b,
                              kde_float3* centers_b, const float* intr_dev, hipStream_t s)
 {
     AnalyzeSets sets;
     sets.s[0] = AnalyzeSet{labels_a, mean_a, centers_a};
     sets.s[1] = AnalyzeSet{labels_b, mean_b, centers_b};
-    hipLaunchKernelGGL(analyze_clusters_kernel, dim3(g.cols, g.rows, 2), dim3(256), 0, s, g, bgr, pts, sets, intr_dev);
+    sets.nsets = 2;
+    hipLaunchKernelGGL(analyze_clusters_kernel, dim3(g.cols, g.rows, 2 * n), dim3(256), 0, s, g, bgr, pts, sets, intr_dev);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }

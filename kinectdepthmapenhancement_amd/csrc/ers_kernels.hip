@@ -205,7 +205,13 @@ __global__ __launch_bounds__(256) void edge_fused_kernel(int width, int height,
 
     const int tid = threadIdx.x;
     const unsigned tiles_x = (unsigned)((width + kEdgeTX - 1) / kEdgeTX);
-    const unsigned tile = xcd_band_id(blockIdx.x, gridDim.x);       // 1-D grid of tiles_x * tiles_y workgroups
+    const unsigned tiles = tiles_x * (unsigned)((height + kEdgeTY - 1) / kEdgeTY);
+    const unsigned gid = xcd_band_id(blockIdx.x, gridDim.x);        // 1-D grid of frames * tiles_x * tiles_y workgroups
+    const unsigned frame = gid / tiles, tile = gid - frame * tiles;
+    {   // a batch of frames: every plane of frame f starts f * width * height elements further
+        const size_t fpx = (size_t)frame * width * height;
+        color_labels += fpx; L0 += fpx; D0 += fpx; L2 += fpx; D2 += fpx;
+    }
     const int x0 = (int)(tile % tiles_x) * kEdgeTX, y0 = (int)(tile / tiles_x) * kEdgeTY;
     {
         // Staging.  Every load is issued before the first one is consumed: addresses are clamped into the image
@@ -713,7 +719,14 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
     __shared__ uint32_t s_rng[2];                 // bit patterns of the smallest / largest valid depth staged (tile + halo)
 
     const unsigned tiles_x = (unsigned)((a.width + TW - 1) / TW);
-    const unsigned tile = xcd_band_id(blockIdx.x, gridDim.x);       // 1-D grid of tiles_x * tiles_y workgroups
+    const unsigned tiles = tiles_x * (unsigned)((a.height + TH - 1) / TH);
+    const unsigned gid = xcd_band_id(blockIdx.x, gridDim.x);        // 1-D grid of frames * tiles_x * tiles_y workgroups
+    const unsigned frame = gid / tiles, tile = gid - frame * tiles;
+    const size_t fpx = (size_t)frame * a.width * a.height;          // a batch of frames: planes of frame f start f * W * H further
+    const float* __restrict__ in_rd = a.rd + fpx;
+    const uint8_t* __restrict__ in_bgr = a.bgr + fpx * 3;
+    const int32_t* __restrict__ in_labels = a.labels + fpx;
+    float* __restrict__ out_d = a.out + fpx;
     const int x0 = (int)(tile % tiles_x) * TW, y0 = (int)(tile / tiles_x) * TH;
     const int tid = threadIdx.x;
     if (tid < 2) s_rng[tid] = tid == 0 ? 0x7f800000u : 0u;
@@ -727,9 +740,9 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
         int32_t l = 0;
         if (gx >= 0 && gx < a.width && gy >= 0 && gy < a.height) {
             const size_t q = (size_t)gy * a.width + gx;
-            d = a.rd[q];
-            c = load_bgrx(a.bgr, q);
-            l = a.labels[q];
+            d = in_rd[q];
+            c = load_bgrx(in_bgr, q);
+            l = in_labels[q];
         }
         const bool valid = d > 50.0f;
         s_d[i] = valid ? d : 0.0f;
@@ -791,8 +804,8 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
         cc[h] = s_c[(ty + R) * P + sx + R + h] & 0x00ffffffu;
         negC[h] = -(kBiasF + (float)dot4u(cc[h], cc[h]));
     }
-    cl.x = (float)a.labels[p];                               // the centre's label counts even if its depth is invalid
-    cl.y = has1 ? (float)a.labels[p + 1] : 2.0e9f;
+    cl.x = (float)in_labels[p];                               // the centre's label counts even if its depth is invalid
+    cl.y = has1 ? (float)in_labels[p + 1] : 2.0e9f;
 
     // unit u of a row: (tap of p0, tap of p1) taken from ONE aligned LDS pair -- straight / swapped / leftover
     auto pick_u = [&](const e_u2* v, int u, uint32_t& v0, uint32_t& v1) {
@@ -1047,11 +1060,11 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
         if (flat[0] && wgt.x > 0.0f && nan0) res[0] = __builtin_nanf("");
         if (flat[1] && wgt.y > 0.0f && nan1) res[1] = __builtin_nanf("");
     }
-    a.out[p] = res[0];
-    if (has1) a.out[p + 1] = res[1];
+    out_d[p] = res[0];
+    if (has1) out_d[p + 1] = res[1];
     KDE_STAGE(if (a.stage_avg) {
-        a.stage_avg[p] = wavg.x;
-        if (has1) a.stage_avg[p + 1] = wavg.y;
+        (a.stage_avg + fpx)[p] = wavg.x;
+        if (has1) (a.stage_avg + fpx)[p + 1] = wavg.y;
     })
     KDE_STAGE(if (a.stage_dev) {
         if (!stage_dev_done) {        // the product path never needed this pixel's deviation: form it for the dump only
@@ -1060,8 +1073,8 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
             adaptive_sigma();
             inv_a = keep_inv; nthr_a = keep_thr; flat[0] = keep_flat[0]; flat[1] = keep_flat[1];
         }
-        a.stage_dev[p] = stage_dev2[0];
-        if (has1) a.stage_dev[p + 1] = stage_dev2[1];
+        (a.stage_dev + fpx)[p] = stage_dev2[0];
+        if (has1) (a.stage_dev + fpx)[p + 1] = stage_dev2[1];
     })
 }
 
@@ -1080,26 +1093,54 @@ int launch_ers_edge_phase(int width, int height, int dir, int window, const int3
 }
 
 // both phases; scratch_l / scratch_d hold the horizontal result only when the window is too wide for the fused kernel
-int launch_ers_edge_refining(int width, int height, int window, const int32_t* color_labels, const int32_t* l0,
+int launch_ers_edge_refining(int width, int height, int n, int window, const int32_t* color_labels, const int32_t* l0,
                              const float* d0, int32_t* scratch_l, float* scratch_d, int32_t* l2, float* d2, bool two_launches,
                              hipStream_t s)
 {
     // The fused kernel's halos (colour labels +-(2 + window/2), depth labels / depth -2..+3) and register window are
     // laid out for the reference's window of 7 (EdgeRefinedSuperpixel.cpp:4); any other window runs the two-launch
     // form, whose rule takes any reach.
-    if (!two_launches && window / 2 == 3) {
-        const dim3 grid(ceil_div(width, kEdgeTX) * ceil_div(height, kEdgeTY));
+    const long long tiles = (long long)ceil_div(width, kEdgeTX) * ceil_div(height, kEdgeTY);
+    if (!two_launches && window / 2 == 3 && tiles * n <= 0x7fffffffLL) {
+        const dim3 grid((unsigned)(tiles * n));          // all frames of the batch in one launch
         hipLaunchKernelGGL(edge_fused_kernel<3>, grid, dim3(256), 0, s, width, height, color_labels, l0, d0, l2, d2);
         KDE_HIP_TRY(hipGetLastError());
         return KDE_OK;
     }
-    KDE_TRY(launch_ers_edge_phase(width, height, 0, window, color_labels, l0, d0, scratch_l, scratch_d, s));
-    return launch_ers_edge_phase(width, height, 1, window, color_labels, scratch_l, scratch_d, l2, d2, s);
+    const size_t px = (size_t)width * height;
+    for (int f = 0; f < n; f++) {                        // the two-launch form works frame by frame (one frame of scratch)
+        KDE_TRY(launch_ers_edge_phase(width, height, 0, window, color_labels + f * px, l0 + f * px, d0 + f * px, scratch_l, scratch_d, s));
+        KDE_TRY(launch_ers_edge_phase(width, height, 1, window, color_labels + f * px, scratch_l, scratch_d, l2 + f * px, d2 + f * px, s));
+    }
+    return KDE_OK;
 }
 
-int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr, const int32_t* labels,
+static int launch_ers_enhance_one(int width, int height, int n, const float* rd, const uint8_t* bgr, const int32_t* labels,
+                                  const float* s_eff, const float* table_host, int window, float color_sigma, float depth_sigma,
+                                  float exp_zero, float* out, int variant, hipStream_t s);
+
+// n frames back to back: the packed kernel takes the whole batch in one launch, the fall-back kernels go frame by frame
+int launch_ers_enhance(int width, int height, int n, const float* rd, const uint8_t* bgr, const int32_t* labels,
                        const float* s_eff, const float* table_host, int window, float color_sigma, float depth_sigma,
                        float exp_zero, float* out, int variant, hipStream_t s)
+{
+    const float cden = 2 * (color_sigma * color_sigma);
+    const bool tuned = window == 7 && color_sigma != 0.0f && depth_sigma != 0.0f && !(195075.0f / cden >= exp_zero);
+    const bool can_pk = tuned && (long long)width * height <= (1LL << 24);
+    const long long blocks = (long long)ceil_div(width, 64) * ceil_div(height, 8) * n;
+    if (n == 1 || (((variant == 0 && can_pk) || variant == 1) && blocks <= 0x7fffffffLL))
+        return launch_ers_enhance_one(width, height, n, rd, bgr, labels, s_eff, table_host, window, color_sigma, depth_sigma,
+                                      exp_zero, out, variant, s);
+    const size_t px = (size_t)width * height;
+    for (int f = 0; f < n; f++)
+        KDE_TRY(launch_ers_enhance_one(width, height, 1, rd + f * px, bgr + f * px * 3, labels + f * px, s_eff, table_host, window,
+                                       color_sigma, depth_sigma, exp_zero, out + f * px, variant, s));
+    return KDE_OK;
+}
+
+static int launch_ers_enhance_one(int width, int height, int n, const float* rd, const uint8_t* bgr, const int32_t* labels,
+                                  const float* s_eff, const float* table_host, int window, float color_sigma, float depth_sigma,
+                                  float exp_zero, float* out, int variant, hipStream_t s)
 {
     const float cden = 2 * (color_sigma * color_sigma);
     // tuned kernels: 7x7 window, both sigmas on, pass-1 colour factor can never underflow
@@ -1166,7 +1207,7 @@ int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bg
         for (int k = 49; k >= 1 && d.tthr[k] >= -1.0f; k--) d.kfree = k;
         KDE_STAGE(d.stage_avg = g_stage.ers_avg; d.stage_dev = g_stage.ers_dev; d.stage_counters = g_stage.counters;
                   d.stage_force = g_stage.force_full_rules;)
-        hipLaunchKernelGGL(enhance7_pk_kernel, dim3(ceil_div(width, kE7BX * 2) * ceil_div(height, kE7BY)),
+        hipLaunchKernelGGL(enhance7_pk_kernel, dim3((unsigned)(ceil_div(width, kE7BX * 2) * ceil_div(height, kE7BY) * n)),
                            dim3(kE7BX * kE7BY), 0, s, d);
         KDE_HIP_TRY(hipGetLastError());
         return KDE_OK;

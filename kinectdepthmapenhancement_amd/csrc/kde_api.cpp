@@ -27,6 +27,25 @@ StageCtl g_stage = {nullptr, nullptr, nullptr, nullptr, 0};
 
 using namespace kde;
 
+// A handle belongs to the device that was current when it was created (its buffers live there).  Calls made while
+// another device is current are rejected instead of launching kernels on the wrong device's memory.
+static int current_device()
+{
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return d;
+}
+#define KDE_ON_DEVICE(h, who)                                                                                              \
+    do {                                                                                                                   \
+        const int cur_ = current_device();                                                                                 \
+        if (cur_ != (h)->device)                                                                                           \
+            return fail(KDE_ERR_INVALID, "%s: the handle was created on device %d but device %d is current (kde_set_device)", \
+                        who, (h)->device, cur_);                                                                           \
+    } while (0)
+
 #ifdef KDE_STAGE_HOOKS
 // include/kde_test_hooks.h: exists only in tools/hooks/libkde_hip_stage.so
 extern "C" int kde_stage_set(float* jbf_avg_dev, float* ers_avg_dev, float* ers_dev_dev, unsigned* counters_dev, int force_full_rules)
@@ -74,6 +93,7 @@ extern "C" int kde_device_info(char* arch_buf, size_t arch_cap, int* cu_count)
 // JointBilateralFilter
 // =====================================================================================================
 struct kde_jbf {
+    int device = -1;                // hipGetDevice() at creation
     int width = 0, height = 0, max_batch = 1;
     kde_jbf_params p{};
     std::vector<float> table;       // SpatialFilter_Host
@@ -139,6 +159,7 @@ static int jbf_create_impl(kde_jbf** out, int width, int height, int max_batch, 
     } guard{new (std::nothrow) kde_jbf};
     kde_jbf* h = guard.h;
     if (!h) return fail(KDE_ERR_NOMEM, "kde_jbf_create: out of host memory");
+    h->device = current_device();
     h->width = width;
     h->height = height;
     h->max_batch = max_batch;
@@ -238,6 +259,7 @@ extern "C" int kde_jbf_process_batch(kde_jbf* h, int n, const float* depth_dev, 
                                      float* filtered_dev, void* stream)
 {
     KDE_REQUIRE(h && depth_dev && bgr_dev, "kde_jbf_process_batch: null argument");
+    KDE_ON_DEVICE(h, "kde_jbf_process_batch");
     KDE_REQUIRE(n >= 1 && n <= h->max_batch, "kde_jbf_process_batch: n=%d outside 1..max_batch=%d", n, h->max_batch);
     hipStream_t s = as_stream(stream);
     float* out = filtered_dev ? filtered_dev : h->filtered.p;
@@ -261,6 +283,7 @@ extern "C" int kde_jbf_process(kde_jbf* h, const float* depth_dev, const uint8_t
 extern "C" int kde_jbf_presmooth_batch(kde_jbf* h, int n, const uint8_t* bgr_dev, uint8_t* smooth_dev, void* stream)
 {
     KDE_REQUIRE(h && bgr_dev, "kde_jbf_presmooth_batch: null argument");
+    KDE_ON_DEVICE(h, "kde_jbf_presmooth_batch");
     KDE_REQUIRE(h->p.presmooth, "kde_jbf_presmooth_batch: handle was created with presmooth = 0");
     KDE_REQUIRE(n >= 1 && (smooth_dev || n <= h->max_batch), "kde_jbf_presmooth_batch: bad n");
     return jbf_presmooth(h, n, bgr_dev, smooth_dev ? smooth_dev : h->smooth.p, as_stream(stream));
@@ -270,6 +293,7 @@ extern "C" int kde_jbf_filter_batch(kde_jbf* h, int n, const float* depth_dev, c
                                     float* filtered_dev, void* stream)
 {
     KDE_REQUIRE(h && depth_dev && guide_bgr_dev, "kde_jbf_filter_batch: null argument");
+    KDE_ON_DEVICE(h, "kde_jbf_filter_batch");
     KDE_REQUIRE(n >= 1 && n <= 65535 && (filtered_dev || n <= h->max_batch), "kde_jbf_filter_batch: bad n");
     float* out = filtered_dev ? filtered_dev : h->filtered.p;
     KDE_TRY(jbf_filter(h, n, depth_dev, guide_bgr_dev, out, as_stream(stream)));
@@ -287,6 +311,7 @@ extern "C" int kde_jbf_filtered_device(kde_jbf* h, float** out)
 extern "C" int kde_jbf_filtered_host(kde_jbf* h, void* stream, const float** out)
 {
     KDE_REQUIRE(h && out, "kde_jbf_filtered_host: null argument");
+    KDE_ON_DEVICE(h, "kde_jbf_filtered_host");
     // Filtered_Host mirrors the object's own Filtered_Device (JointBilateralFilter.cpp:45-49): n_last <= max_batch
     // frames of it, never a caller-owned output buffer (which may be larger than the pinned buffer, or freed)
     const int frames = h->n_last > 0 ? (h->n_last < h->max_batch ? h->n_last : h->max_batch) : 1;
@@ -328,9 +353,12 @@ extern "C" const char* kde_jbf_variant_name(int variant) { return jbf_variant_na
 // MarkovRandomField
 // =====================================================================================================
 struct kde_mrf {
+    int device = -1;
     int width, height, max_batch, window;
     float color_sigma, smooth_sigma;
-    DevBuf<float> filtered;
+    DevBuf<float> filtered;          // Filtered_Device
+    PinnedBuf<float> filtered_host;  // Filtered_Host (MarkovRandomField.h:16)
+    int n_last = 0;                  // frames of the last call that wrote Filtered_Device
 };
 
 extern "C" int kde_mrf_create(kde_mrf** out, int width, int height, int max_batch, int window, float color_sigma, float smooth_sigma)
@@ -344,6 +372,7 @@ extern "C" int kde_mrf_create(kde_mrf** out, int width, int height, int max_batc
     KDE_REQUIRE(window <= 31 && (window & 1), "kde_mrf_create: window must be odd <= 31");
     kde_mrf* h = new (std::nothrow) kde_mrf;
     if (!h) return fail(KDE_ERR_NOMEM, "kde_mrf_create: out of host memory");
+    h->device = current_device();
     h->width = width; h->height = height; h->max_batch = max_batch; h->window = window;
     h->color_sigma = color_sigma; h->smooth_sigma = smooth_sigma;
     int rc = h->filtered.alloc((size_t)width * height * max_batch);
@@ -357,10 +386,28 @@ extern "C" int kde_mrf_destroy(kde_mrf* h) { delete h; return KDE_OK; }
 extern "C" int kde_mrf_process_batch(kde_mrf* h, int n, const float* depth_dev, const uint8_t* bgr_dev, float* filtered_dev, void* stream)
 {
     KDE_REQUIRE(h && depth_dev && bgr_dev, "kde_mrf_process_batch: null argument");
+    KDE_ON_DEVICE(h, "kde_mrf_process_batch");
     KDE_REQUIRE(n >= 1 && n <= 65535 && (filtered_dev || n <= h->max_batch), "kde_mrf_process_batch: bad n");
     MrfLaunch a{h->width, h->height, n, h->window, depth_dev, bgr_dev, filtered_dev ? filtered_dev : h->filtered.p,
                 h->color_sigma, h->smooth_sigma};
-    return launch_mrf(a, as_stream(stream));
+    KDE_TRY(launch_mrf(a, as_stream(stream)));
+    if (!filtered_dev) h->n_last = n;
+    return KDE_OK;
+}
+
+// float* MarkovRandomField::getFiltered_Host() (MarkovRandomField.h:16; the reference refreshes it after every Process,
+// MarkovRandomField.cu:48): here a lazy copy of the object's own Filtered_Device, never of a caller's output buffer
+extern "C" int kde_mrf_filtered_host(kde_mrf* h, void* stream, const float** out)
+{
+    KDE_REQUIRE(h && out, "kde_mrf_filtered_host: null argument");
+    KDE_ON_DEVICE(h, "kde_mrf_filtered_host");
+    const int frames = h->n_last > 0 ? (h->n_last < h->max_batch ? h->n_last : h->max_batch) : 1;
+    const size_t count = (size_t)h->width * h->height * frames;
+    KDE_TRY(h->filtered_host.ensure((size_t)h->width * h->height * h->max_batch));
+    KDE_HIP_TRY(hipMemcpyAsync(h->filtered_host.p, h->filtered.p, count * sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
+    KDE_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    *out = h->filtered_host.p;
+    return KDE_OK;
 }
 
 extern "C" int kde_mrf_filtered_device(kde_mrf* h, float** out)
@@ -440,6 +487,7 @@ extern "C" int kde_dimconv_real_to_projective(kde_dimconv* h, int n, const kde_f
 // Buffer2D
 // =====================================================================================================
 struct kde_buffer2d {
+    int device = -1;
     int width, height;
     DevBuf<kde_weighted_d> buf;   // devPtr
 };
@@ -451,6 +499,7 @@ extern "C" int kde_buffer2d_create(kde_buffer2d** out, int width, int height)
     KDE_REQUIRE(width >= 1 && height >= 1 && (long long)width * height <= (1ll << 30), "kde_buffer2d_create: bad size");
     kde_buffer2d* h = new (std::nothrow) kde_buffer2d;
     if (!h) return fail(KDE_ERR_NOMEM, "kde_buffer2d_create: out of host memory");
+    h->device = current_device();
     h->width = width;
     h->height = height;
     int rc = h->buf.alloc((size_t)width * height);
@@ -466,18 +515,21 @@ extern "C" int kde_buffer2d_destroy(kde_buffer2d* h) { delete h; return KDE_OK; 
 extern "C" int kde_buffer2d_insert_depth(kde_buffer2d* h, const float* depth_dev, void* stream)
 {
     KDE_REQUIRE(h && depth_dev, "kde_buffer2d_insert_depth: null argument");
+    KDE_ON_DEVICE(h, "kde_buffer2d_insert_depth");
     return launch_buf_insert_depth(h->buf.p, depth_dev, h->buf.n, as_stream(stream));
 }
 
 extern "C" int kde_buffer2d_insert_float2(kde_buffer2d* h, const float* xy_dev, void* stream)
 {
     KDE_REQUIRE(h && xy_dev, "kde_buffer2d_insert_float2: null argument");
+    KDE_ON_DEVICE(h, "kde_buffer2d_insert_float2");
     return launch_buf_insert_float2(h->buf.p, xy_dev, h->width, h->height, as_stream(stream));
 }
 
 extern "C" int kde_buffer2d_insert_weighted(kde_buffer2d* h, const kde_weighted_d* data_dev, void* stream)
 {
     KDE_REQUIRE(h && data_dev, "kde_buffer2d_insert_weighted: null argument");
+    KDE_ON_DEVICE(h, "kde_buffer2d_insert_weighted");
     KDE_HIP_TRY(hipMemcpyAsync(h->buf.p, data_dev, h->buf.n * sizeof(kde_weighted_d), hipMemcpyDeviceToDevice, as_stream(stream)));
     return KDE_OK;
 }
@@ -485,18 +537,21 @@ extern "C" int kde_buffer2d_insert_weighted(kde_buffer2d* h, const kde_weighted_
 extern "C" int kde_buffer2d_get_depth_map(kde_buffer2d* h, float* out_dev, void* stream)
 {
     KDE_REQUIRE(h && out_dev, "kde_buffer2d_get_depth_map: null argument");
+    KDE_ON_DEVICE(h, "kde_buffer2d_get_depth_map");
     return launch_buf_get(h->buf.p, out_dev, h->buf.n, 0, as_stream(stream));
 }
 
 extern "C" int kde_buffer2d_get_weight_map(kde_buffer2d* h, float* out_dev, void* stream)
 {
     KDE_REQUIRE(h && out_dev, "kde_buffer2d_get_weight_map: null argument");
+    KDE_ON_DEVICE(h, "kde_buffer2d_get_weight_map");
     return launch_buf_get(h->buf.p, out_dev, h->buf.n, 1, as_stream(stream));
 }
 
 extern "C" int kde_buffer2d_update_sequence(kde_buffer2d* h, int n_frames, const float* depth_dev, void* stream)
 {
     KDE_REQUIRE(h && depth_dev, "kde_buffer2d_update: null argument");
+    KDE_ON_DEVICE(h, "kde_buffer2d_update");
     KDE_REQUIRE(n_frames >= 1, "kde_buffer2d_update: n_frames must be >= 1");
     return launch_buf_update(h->buf.p, depth_dev, h->buf.n, n_frames, as_stream(stream));
 }
@@ -517,13 +572,15 @@ extern "C" int kde_buffer2d_raw_pointer(kde_buffer2d* h, kde_weighted_d** out)
 // DepthAdaptiveSuperpixel
 // =====================================================================================================
 struct kde_dasp {
+    int device = -1;
     int width, height;
+    int max_batch = 1;                   // > 1 only for the private segmenters of a batched pipeline object
     bool set = false;
     DaspGeom g{};
-    DevBuf<int32_t> labels;              // Labels_Device
-    DevBuf<kde_label_distance> ld;       // LD_Device
-    DevBuf<kde_superpixel> mean;         // meanData_Device
-    DevBuf<kde_float3> centers;          // superpixelCenters_Device
+    DevBuf<int32_t> labels;              // Labels_Device                [max_batch][H][W]
+    DevBuf<kde_label_distance> ld;       // LD_Device                    [max_batch][H][W]
+    DevBuf<kde_superpixel> mean;         // meanData_Device              [max_batch][rows*cols]
+    DevBuf<kde_float3> centers;          // superpixelCenters_Device     [max_batch][rows*cols]
     DevBuf<float> intr;                  // intrinsicDevice
     PinnedBuf<int32_t> labels_host;      // Labels_Host
     // Set by the pipeline objects (RGBF / SPDSR) for their PRIVATE segmenters: the analyzeClusters that
@@ -532,16 +589,19 @@ struct kde_dasp {
     bool skip_trailing_analyze = false;
 };
 
-extern "C" int kde_dasp_create(kde_dasp** out, int width, int height)
+static int dasp_create_impl(kde_dasp** out, int width, int height, int max_batch)
 {
     KDE_REQUIRE(out, "kde_dasp_create: null out");
     *out = nullptr;
     KDE_REQUIRE(width >= 1 && height >= 1 && (long long)width * height <= (1ll << 30), "kde_dasp_create: bad size");
+    KDE_REQUIRE(max_batch >= 1 && max_batch <= 65535, "create: max_batch must be in 1..65535");
     kde_dasp* h = new (std::nothrow) kde_dasp;
     if (!h) return fail(KDE_ERR_NOMEM, "kde_dasp_create: out of host memory");
+    h->device = current_device();
     h->width = width;
     h->height = height;
-    const size_t px = (size_t)width * height;
+    h->max_batch = max_batch;
+    const size_t px = (size_t)width * height * max_batch;
     int rc = h->labels.alloc(px);                 // SuperpixelSegmentation.cpp (ctor)
     if (rc == KDE_OK) rc = h->ld.alloc(px);
     if (rc == KDE_OK) rc = h->intr.alloc(9);      // DepthAdaptiveSuperpixel.cpp:6
@@ -549,6 +609,8 @@ extern "C" int kde_dasp_create(kde_dasp** out, int width, int height)
     *out = h;
     return KDE_OK;
 }
+
+extern "C" int kde_dasp_create(kde_dasp** out, int width, int height) { return dasp_create_impl(out, width, height, 1); }
 
 extern "C" int kde_dasp_destroy(kde_dasp* h) { delete h; return KDE_OK; }
 
@@ -566,9 +628,10 @@ static int dasp_geometry(int width, int height, int rows, int cols, DaspGeom* g)
 extern "C" int kde_dasp_set_parameters(kde_dasp* h, int rows, int cols, const double* K)
 {
     KDE_REQUIRE(h && K, "kde_dasp_set_parameters: null argument");
+    KDE_ON_DEVICE(h, "kde_dasp_set_parameters");
     DaspGeom g;
     KDE_TRY(dasp_geometry(h->width, h->height, rows, cols, &g));
-    const size_t k = (size_t)rows * cols;
+    const size_t k = (size_t)rows * cols * h->max_batch;
     KDE_TRY(h->mean.alloc(k));       // initMemory, DepthAdaptiveSuperpixel.cpp:40-50
     KDE_TRY(h->centers.alloc(k));
     KDE_HIP_TRY(hipMemset(h->mean.p, 0, k * sizeof(kde_superpixel)));
@@ -585,6 +648,7 @@ extern "C" int kde_dasp_segmentation(kde_dasp* h, const uint8_t* bgr_dev, const 
                                      float color_sigma, float spatial_sigma, float depth_sigma, int iteration, void* stream)
 {
     KDE_REQUIRE(h && bgr_dev && points_dev, "kde_dasp_segmentation: null argument");
+    KDE_ON_DEVICE(h, "kde_dasp_segmentation");
     KDE_REQUIRE(h->set, "kde_dasp_segmentation: SetParametor was not called");
     KDE_REQUIRE(iteration >= 0, "kde_dasp_segmentation: negative iteration count");
     // the weights are (sigma / sum of sigmas)^2 (.cu:209-217): a zero sum is 0/0 in the reference
@@ -592,7 +656,7 @@ extern "C" int kde_dasp_segmentation(kde_dasp* h, const uint8_t* bgr_dev, const 
     hipStream_t s = as_stream(stream);
     // DepthAdaptiveSuperpixel.cu:570-586
     // init_LD (K5) is folded into the first calculateLD: its output is only ever read there
-    KDE_TRY(launch_dasp_sample(h->g, bgr_dev, points_dev, h->mean.p, h->centers.p, s));
+    KDE_TRY(launch_dasp_sample(h->g, 1, bgr_dev, points_dev, h->mean.p, h->centers.p, s));
     for (int i = 0; i < iteration; i++) {
         KDE_TRY(launch_dasp_calc_ld(h->g, bgr_dev, points_dev, h->ld.p, h->mean.p, h->centers.p, h->labels.p,
                                     color_sigma, spatial_sigma, depth_sigma, i == 0, s));
@@ -633,6 +697,7 @@ extern "C" int kde_dasp_ld_device(kde_dasp* h, kde_label_distance** out)
 extern "C" int kde_dasp_labels_host(kde_dasp* h, void* stream, const int32_t** out)
 {
     KDE_REQUIRE(h && out, "kde_dasp_labels_host: null argument");
+    KDE_ON_DEVICE(h, "kde_dasp_labels_host");
     const size_t px = (size_t)h->width * h->height;
     KDE_TRY(h->labels_host.ensure(px));
     KDE_HIP_TRY(hipMemcpyAsync(h->labels_host.p, h->labels.p, px * sizeof(int32_t), hipMemcpyDeviceToHost, as_stream(stream)));
@@ -645,15 +710,18 @@ extern "C" int kde_dasp_labels_host(kde_dasp* h, void* stream, const int32_t** o
 // EdgeRefinedSuperpixel
 // =====================================================================================================
 struct kde_ers {
+    int device = -1;
     int width, height;
+    int max_batch = 1;                    // > 1 only inside a batched pipeline object
+    int n_last = 1;                       // frames of the last EdgeRefining
     static constexpr int WindowSize = 7;            // EdgeRefinedSuperpixel.cpp:4
     static constexpr float SpatialSigma = 30.0f;    // :5
     static constexpr float ColorSigma = 50.0f;      // :6
     static constexpr float DepthSigma = 70.0f;      // :7
     DevBuf<float> s_eff;                  // SpatialFilter_Device
-    DevBuf<int32_t> labels_a, labels_b;   // refinedLabels_Device + phase scratch
-    DevBuf<float> depth_a, depth_b;       // K9 phase buffers
-    DevBuf<float> refined_depth;          // refinedDepth_Device
+    DevBuf<int32_t> labels_a, labels_b;   // refinedLabels_Device [max_batch] + one frame of phase scratch
+    DevBuf<float> depth_a, depth_b;       // K9 result [max_batch] + one frame of phase scratch
+    DevBuf<float> refined_depth;          // refinedDepth_Device [max_batch]
     PinnedBuf<int32_t> labels_host;
     PinnedBuf<float> depth_host;
     float exp_zero = 0;
@@ -661,15 +729,18 @@ struct kde_ers {
     int enhance_variant = 0;              // kde_ers_set_variant
 };
 
-extern "C" int kde_ers_create(kde_ers** out, int width, int height)
+static int ers_create_impl(kde_ers** out, int width, int height, int max_batch)
 {
     KDE_REQUIRE(out, "kde_ers_create: null out");
     *out = nullptr;
     KDE_REQUIRE(width >= 1 && height >= 1 && (long long)width * height <= (1ll << 30), "kde_ers_create: bad size");
+    KDE_REQUIRE(max_batch >= 1 && max_batch <= 65535, "create: max_batch must be in 1..65535");
     kde_ers* h = new (std::nothrow) kde_ers;
     if (!h) return fail(KDE_ERR_NOMEM, "kde_ers_create: out of host memory");
+    h->device = current_device();
     h->width = width;
     h->height = height;
+    h->max_batch = max_batch;
     h->exp_zero = exp_zero_threshold();
     const size_t px = (size_t)width * height;
     float table[49];
@@ -678,11 +749,11 @@ extern "C" int kde_ers_create(kde_ers** out, int width, int height)
     for (float& v : table)
         if (v == 0.0f) v = 1.0f;
     int rc = h->s_eff.alloc(49);
-    if (rc == KDE_OK) rc = h->labels_a.alloc(px);
+    if (rc == KDE_OK) rc = h->labels_a.alloc(px * max_batch);
     if (rc == KDE_OK) rc = h->labels_b.alloc(px);
-    if (rc == KDE_OK) rc = h->depth_a.alloc(px);
+    if (rc == KDE_OK) rc = h->depth_a.alloc(px * max_batch);
     if (rc == KDE_OK) rc = h->depth_b.alloc(px);
-    if (rc == KDE_OK) rc = h->refined_depth.alloc(px);
+    if (rc == KDE_OK) rc = h->refined_depth.alloc(px * max_batch);
     if (rc == KDE_OK && hipMemcpy(h->s_eff.p, table, sizeof(table), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(KDE_ERR_HIP, "kde_ers_create: table upload failed");
     if (rc != KDE_OK) { delete h; return rc; }
@@ -690,25 +761,37 @@ extern "C" int kde_ers_create(kde_ers** out, int width, int height)
     return KDE_OK;
 }
 
+extern "C" int kde_ers_create(kde_ers** out, int width, int height) { return ers_create_impl(out, width, height, 1); }
+
 extern "C" int kde_ers_destroy(kde_ers* h) { delete h; return KDE_OK; }
 
-extern "C" int kde_ers_edge_refining(kde_ers* h, const int32_t* color_labels_dev, const int32_t* depth_labels_dev,
-                                     const float* depth_dev, const uint8_t* bgr_dev, void* stream)
+// n frames back to back in every argument (n = 1: the reference's call)
+static int ers_edge_refining_n(kde_ers* h, int n, const int32_t* color_labels_dev, const int32_t* depth_labels_dev,
+                               const float* depth_dev, const uint8_t* bgr_dev, void* stream)
 {
     KDE_REQUIRE(h && color_labels_dev && depth_labels_dev && depth_dev && bgr_dev, "kde_ers_edge_refining: null argument");
+    KDE_ON_DEVICE(h, "kde_ers_edge_refining");
+    KDE_REQUIRE(n >= 1 && n <= h->max_batch, "EdgeRefining: n=%d outside 1..max_batch=%d", n, h->max_batch);
     hipStream_t s = as_stream(stream);
     const int W = h->width, H = h->height;
     // EdgeRefinedSuperpixel.cu:210-211 copies labels/depth, then edge_refining works in place; here the
     // horizontal phase reads the caller's buffers and the vertical phase reads the horizontal result (kept in
     // LDS by the fused kernel), so the two D2D copies disappear.
-    KDE_TRY(launch_ers_edge_refining(W, H, kde_ers::WindowSize, color_labels_dev, depth_labels_dev, depth_dev,
+    KDE_TRY(launch_ers_edge_refining(W, H, n, kde_ers::WindowSize, color_labels_dev, depth_labels_dev, depth_dev,
                                      h->labels_b.p, h->depth_b.p, h->labels_a.p, h->depth_a.p,
                                      /*two_launches=*/h->enhance_variant == 3, s));
     // depthmap_enhancement (.cu:220-221)
-    KDE_TRY(launch_ers_enhance(W, H, h->depth_a.p, bgr_dev, h->labels_a.p, h->s_eff.p, h->table_host,
+    KDE_TRY(launch_ers_enhance(W, H, n, h->depth_a.p, bgr_dev, h->labels_a.p, h->s_eff.p, h->table_host,
                                kde_ers::WindowSize, kde_ers::ColorSigma, kde_ers::DepthSigma, h->exp_zero,
                                h->refined_depth.p, h->enhance_variant, s));
+    h->n_last = n;
     return KDE_OK;
+}
+
+extern "C" int kde_ers_edge_refining(kde_ers* h, const int32_t* color_labels_dev, const int32_t* depth_labels_dev,
+                                     const float* depth_dev, const uint8_t* bgr_dev, void* stream)
+{
+    return ers_edge_refining_n(h, 1, color_labels_dev, depth_labels_dev, depth_dev, bgr_dev, stream);
 }
 
 extern "C" int kde_ers_set_variant(kde_ers* h, int variant)
@@ -740,12 +823,14 @@ extern "C" int kde_ers_refined_depth_device(kde_ers* h, float** out)
     return KDE_OK;
 }
 
+// the *_Host getters mirror the frames the last call produced (one for the reference's single-frame calls)
 extern "C" int kde_ers_refined_labels_host(kde_ers* h, void* stream, const int32_t** out)
 {
     KDE_REQUIRE(h && out, "kde_ers_refined_labels_host: null argument");
+    KDE_ON_DEVICE(h, "kde_ers_refined_labels_host");
     const size_t px = (size_t)h->width * h->height;
-    KDE_TRY(h->labels_host.ensure(px));
-    KDE_HIP_TRY(hipMemcpyAsync(h->labels_host.p, h->labels_a.p, px * sizeof(int32_t), hipMemcpyDeviceToHost, as_stream(stream)));
+    KDE_TRY(h->labels_host.ensure(px * h->max_batch));
+    KDE_HIP_TRY(hipMemcpyAsync(h->labels_host.p, h->labels_a.p, px * h->n_last * sizeof(int32_t), hipMemcpyDeviceToHost, as_stream(stream)));
     KDE_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     *out = h->labels_host.p;
     return KDE_OK;
@@ -754,9 +839,10 @@ extern "C" int kde_ers_refined_labels_host(kde_ers* h, void* stream, const int32
 extern "C" int kde_ers_refined_depth_host(kde_ers* h, void* stream, const float** out)
 {
     KDE_REQUIRE(h && out, "kde_ers_refined_depth_host: null argument");
+    KDE_ON_DEVICE(h, "kde_ers_refined_depth_host");
     const size_t px = (size_t)h->width * h->height;
-    KDE_TRY(h->depth_host.ensure(px));
-    KDE_HIP_TRY(hipMemcpyAsync(h->depth_host.p, h->refined_depth.p, px * sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
+    KDE_TRY(h->depth_host.ensure(px * h->max_batch));
+    KDE_HIP_TRY(hipMemcpyAsync(h->depth_host.p, h->refined_depth.p, px * h->n_last * sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
     KDE_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     *out = h->depth_host.p;
     return KDE_OK;
@@ -766,7 +852,7 @@ extern "C" int kde_ers_refined_depth_host(kde_ers* h, void* stream, const float*
 // RegionGrowingBilateralFilter / SPDepthSuperResolution (pipeline objects)
 // =====================================================================================================
 struct Pipeline {
-    int width = 0, height = 0;
+    int width = 0, height = 0, max_batch = 1;
     kde_dasp* SP = nullptr;     // colour segmentation
     kde_dasp* DASP = nullptr;   // depth-adaptive segmentation
     kde_ers* ERS = nullptr;
@@ -776,46 +862,53 @@ struct Pipeline {
         kde_dasp_destroy(DASP);
         kde_ers_destroy(ERS);
     }
-    int init(int w, int h)
+    int init(int w, int h, int batch)
     {
         width = w;
         height = h;
-        KDE_TRY(kde_dasp_create(&DASP, w, h));
-        KDE_TRY(kde_dasp_create(&SP, w, h));
+        max_batch = batch;
+        KDE_TRY(dasp_create_impl(&DASP, w, h, batch));
+        KDE_TRY(dasp_create_impl(&SP, w, h, batch));
         DASP->skip_trailing_analyze = SP->skip_trailing_analyze = true;
-        KDE_TRY(kde_ers_create(&ERS, w, h));
+        KDE_TRY(ers_create_impl(&ERS, w, h, batch));
         return KDE_OK;
     }
-    int run(const float* depth, const kde_float3* pts, const uint8_t* bgr, float c1, float s1, float d1, float c2,
+    // n frames back to back in depth / pts / bgr.  Every kernel of the chain takes the whole batch in one launch
+    // (blockIdx -> (frame, tile); per-frame cluster tables, label maps and outputs), so a batch costs the same four
+    // launches as one frame and each frame's result is bit-identical to its single-frame call.
+    int run(int n, const float* depth, const kde_float3* pts, const uint8_t* bgr, float c1, float s1, float d1, float c2,
             float s2, float d2, int iters, void* stream)
     {
         KDE_REQUIRE(SP->set && DASP->set, "Process: SetParametor was not called");
         KDE_REQUIRE(bgr && pts && depth, "Process: null argument");
+        KDE_ON_DEVICE(SP, "Process");
+        KDE_REQUIRE(n >= 1 && n <= max_batch, "Process: n=%d outside 1..max_batch=%d", n, max_batch);
         // SP->Segmentation(...) and DASP->Segmentation(...) (RegionGrowingBilateralFilter.cpp:28-29) run on the same
         // colour + cloud with the same grid, so they share the work that does not depend on the sigmas:
         // sampleInitialClusters is computed once (its result is identical for both) and every assignment step
         // labels both maps in one pass.  Per-object results are exactly those of two separate Segmentation calls.
         hipStream_t s = as_stream(stream);
         const DaspGeom& g = SP->g;
-        const size_t k = (size_t)g.rows * g.cols;
+        const size_t k = (size_t)g.rows * g.cols * n;
         // The first assignment step reads the sampled clusters once for both segmenters and forms init_LD's
         // assignment in registers (calc_ld_kernel<.., FIRST>); DASP's own copy of the sampled clusters is only
         // needed as the starting point of its first analyzeClusters, i.e. when there is more than one iteration.
-        KDE_TRY(launch_dasp_sample(g, bgr, pts, SP->mean.p, SP->centers.p, s));
+        KDE_TRY(launch_dasp_sample(g, n, bgr, pts, SP->mean.p, SP->centers.p, s));
         if (iters > 1) {
             KDE_HIP_TRY(hipMemcpyAsync(DASP->mean.p, SP->mean.p, k * sizeof(kde_superpixel), hipMemcpyDeviceToDevice, s));
             KDE_HIP_TRY(hipMemcpyAsync(DASP->centers.p, SP->centers.p, k * sizeof(kde_float3), hipMemcpyDeviceToDevice, s));
         }
         const float sa[3] = {c1, s1, d1}, sb[3] = {c2, s2, d2};
         for (int i = 0; i < iters; i++) {
-            KDE_TRY(launch_dasp_calc_ld_dual(g, bgr, pts, SP->ld.p, SP->mean.p, SP->centers.p, SP->labels.p, sa, DASP->ld.p,
-                                             DASP->mean.p, DASP->centers.p, DASP->labels.p, sb, i == 0, s));
+            // the (distance, label) records are only read by a LATER assignment step: with one iteration they are not stored
+            KDE_TRY(launch_dasp_calc_ld_dual(g, n, bgr, pts, SP->ld.p, SP->mean.p, SP->centers.p, SP->labels.p, sa, DASP->ld.p,
+                                             DASP->mean.p, DASP->centers.p, DASP->labels.p, sb, i == 0, /*write_ld=*/iters > 1, s));
             if (i == iters - 1) break;   // the trailing analyzeClusters is dead for the private segmenters
             // both objects got the same intrinsics in SetParametor, so one launch updates both cluster sets
-            KDE_TRY(launch_dasp_analyze_dual(g, bgr, pts, SP->labels.p, SP->mean.p, SP->centers.p, DASP->labels.p,
+            KDE_TRY(launch_dasp_analyze_dual(g, n, bgr, pts, SP->labels.p, SP->mean.p, SP->centers.p, DASP->labels.p,
                                              DASP->mean.p, DASP->centers.p, SP->intr.p, s));
         }
-        return kde_ers_edge_refining(ERS, SP->labels.p, DASP->labels.p, depth, bgr, stream);
+        return ers_edge_refining_n(ERS, n, SP->labels.p, DASP->labels.p, depth, bgr, stream);
     }
 };
 
@@ -823,17 +916,20 @@ struct kde_rgbf {
     Pipeline p;
 };
 
-extern "C" int kde_rgbf_create(kde_rgbf** out, int width, int height)
+// max_batch frames per call (kde_rgbf_process_batch); the reference's constructor is max_batch = 1
+extern "C" int kde_rgbf_create_batch(kde_rgbf** out, int width, int height, int max_batch)
 {
     KDE_REQUIRE(out, "kde_rgbf_create: null out");
     *out = nullptr;
     kde_rgbf* h = new (std::nothrow) kde_rgbf;
     if (!h) return fail(KDE_ERR_NOMEM, "kde_rgbf_create: out of host memory");
-    int rc = h->p.init(width, height);
+    int rc = h->p.init(width, height, max_batch);
     if (rc != KDE_OK) { delete h; return rc; }
     *out = h;
     return KDE_OK;
 }
+
+extern "C" int kde_rgbf_create(kde_rgbf** out, int width, int height) { return kde_rgbf_create_batch(out, width, height, 1); }
 
 extern "C" int kde_rgbf_destroy(kde_rgbf* h) { delete h; return KDE_OK; }
 
@@ -844,11 +940,17 @@ extern "C" int kde_rgbf_set_parameters(kde_rgbf* h, int rows, int cols, const do
     return kde_dasp_set_parameters(h->p.DASP, rows, cols, K);      // :25
 }
 
-extern "C" int kde_rgbf_process(kde_rgbf* h, const float* depth_dev, const kde_float3* points_dev, const uint8_t* bgr_dev, void* stream)
+extern "C" int kde_rgbf_process_batch(kde_rgbf* h, int n, const float* depth_dev, const kde_float3* points_dev,
+                                      const uint8_t* bgr_dev, void* stream)
 {
     KDE_REQUIRE(h && depth_dev && points_dev && bgr_dev, "kde_rgbf_process: null argument");
-    // RegionGrowingBilateralFilter.cpp:28-31
-    return h->p.run(depth_dev, points_dev, bgr_dev, 200.0f, 40.0f, 0.0f, 100.0f, 20.0f, 200.0f, 1, stream);
+    // RegionGrowingBilateralFilter.cpp:28-31, per frame
+    return h->p.run(n, depth_dev, points_dev, bgr_dev, 200.0f, 40.0f, 0.0f, 100.0f, 20.0f, 200.0f, 1, stream);
+}
+
+extern "C" int kde_rgbf_process(kde_rgbf* h, const float* depth_dev, const kde_float3* points_dev, const uint8_t* bgr_dev, void* stream)
+{
+    return kde_rgbf_process_batch(h, 1, depth_dev, points_dev, bgr_dev, stream);
 }
 
 extern "C" int kde_rgbf_refined_depth_device(kde_rgbf* h, float** out)
@@ -885,33 +987,36 @@ struct kde_spdsr {
     Pipeline p;
     kde_dimconv conv;
     int nclusters = 0;
-    DevBuf<kde_float3> edge_points;   // EdgeEnhanced3DPoints_Device
-    DevBuf<float> cluster_nd;         // ClusterND_Device (float4 per cluster)
+    DevBuf<kde_float3> edge_points;   // EdgeEnhanced3DPoints_Device            [max_batch][H][W]
+    DevBuf<float> cluster_nd;         // ClusterND_Device (float4 per cluster)   [max_batch][rows*cols]
     DevBuf<double> sums, cov;         // per-cluster moments (replace the host cv::Mat / cv::PCA round trip)
-    DevBuf<float> nxy;                // Projection_GPU::Normalized3D_Device (x, y of the unit-depth ray)
-    DevBuf<kde_float3> plane_fitted;  // Projection_GPU::PlaneFitted3D_Device
+    DevBuf<float> nxy;                // Projection_GPU::Normalized3D_Device (x, y of the unit-depth ray; the camera's)
+    DevBuf<kde_float3> plane_fitted;  // Projection_GPU::PlaneFitted3D_Device    [max_batch][H][W]
     DevBuf<kde_float3> opt_a, opt_b;  // Projection_GPU::Optimized3D_Device, double-buffered (D5)
     kde_float3* optimized = nullptr;
+    int n_last = 1;
     PinnedBuf<kde_float3> optimized_host;
 };
 
-extern "C" int kde_spdsr_create(kde_spdsr** out, int width, int height)
+extern "C" int kde_spdsr_create_batch(kde_spdsr** out, int width, int height, int max_batch)
 {
     KDE_REQUIRE(out, "kde_spdsr_create: null out");
     *out = nullptr;
     kde_spdsr* h = new (std::nothrow) kde_spdsr;
     if (!h) return fail(KDE_ERR_NOMEM, "kde_spdsr_create: out of host memory");
-    int rc = h->p.init(width, height);
+    int rc = h->p.init(width, height, max_batch);
     const size_t px = (size_t)width * height;
-    if (rc == KDE_OK) rc = h->edge_points.alloc(px);   // SPDepthSuperResolution.cpp:19
-    if (rc == KDE_OK) rc = h->nxy.alloc(px * 2);        // Projection_GPU::initMemory (Projection_GPU.cpp:45-51)
-    if (rc == KDE_OK) rc = h->plane_fitted.alloc(px);
-    if (rc == KDE_OK) rc = h->opt_a.alloc(px);
-    if (rc == KDE_OK) rc = h->opt_b.alloc(px);
+    if (rc == KDE_OK) rc = h->edge_points.alloc(px * max_batch);   // SPDepthSuperResolution.cpp:19
+    if (rc == KDE_OK) rc = h->nxy.alloc(px * 2);                    // Projection_GPU::initMemory (Projection_GPU.cpp:45-51)
+    if (rc == KDE_OK) rc = h->plane_fitted.alloc(px * max_batch);
+    if (rc == KDE_OK) rc = h->opt_a.alloc(px * max_batch);
+    if (rc == KDE_OK) rc = h->opt_b.alloc(px * max_batch);
     if (rc != KDE_OK) { delete h; return rc; }
     *out = h;
     return KDE_OK;
 }
+
+extern "C" int kde_spdsr_create(kde_spdsr** out, int width, int height) { return kde_spdsr_create_batch(out, width, height, 1); }
 
 extern "C" int kde_spdsr_destroy(kde_spdsr* h) { delete h; return KDE_OK; }
 
@@ -923,30 +1028,38 @@ extern "C" int kde_spdsr_set_parameters(kde_spdsr* h, int rows, int cols, const 
     KDE_TRY(kde_dimconv_set_camera(&h->conv, K, h->p.width, h->p.height));   // :48
     // Projector = new Projection_GPU(Width, Height, intrinsic) (:49): same truncated intrinsics, initNormalized3D
     h->nclusters = rows * cols;
-    KDE_TRY(h->cluster_nd.alloc((size_t)h->nclusters * 4));          // :52-53
-    KDE_TRY(h->sums.alloc((size_t)h->nclusters * 4));
-    KDE_TRY(h->cov.alloc((size_t)h->nclusters * 6));
-    KDE_HIP_TRY(hipMemset(h->cluster_nd.p, 0, (size_t)h->nclusters * 4 * sizeof(float)));
+    const size_t kb = (size_t)h->nclusters * h->p.max_batch;
+    KDE_TRY(h->cluster_nd.alloc(kb * 4));          // :52-53
+    KDE_TRY(h->sums.alloc(kb * 4));
+    KDE_TRY(h->cov.alloc(kb * 6));
+    KDE_HIP_TRY(hipMemset(h->cluster_nd.p, 0, kb * 4 * sizeof(float)));
     KDE_TRY(launch_spdsr_init_normalized(h->conv.cam, h->nxy.p, nullptr));
     KDE_HIP_TRY(hipStreamSynchronize(nullptr));
     return KDE_OK;
 }
 
-extern "C" int kde_spdsr_process(kde_spdsr* h, const float* depth_dev, const kde_float3* points_dev, const uint8_t* bgr_dev, void* stream)
+extern "C" int kde_spdsr_process_batch(kde_spdsr* h, int n, const float* depth_dev, const kde_float3* points_dev,
+                                       const uint8_t* bgr_dev, void* stream)
 {
     KDE_REQUIRE(h && depth_dev && points_dev && bgr_dev, "kde_spdsr_process: null argument");
-    // SPDepthSuperResolution.cpp:59-64
+    // SPDepthSuperResolution.cpp:59-64, per frame
     KDE_REQUIRE(h->nclusters > 0, "kde_spdsr_process: SetParametor was not called");
-    KDE_TRY(h->p.run(depth_dev, points_dev, bgr_dev, 200.0f, 10.0f, 0.0f, 0.0f, 10.0f, 200.0f, 5, stream));
-    KDE_TRY(kde_dimconv_projective_to_real_depth(&h->conv, 1, h->p.ERS->refined_depth.p, h->edge_points.p, stream));
+    KDE_TRY(h->p.run(n, depth_dev, points_dev, bgr_dev, 200.0f, 10.0f, 0.0f, 0.0f, 10.0f, 200.0f, 5, stream));
+    KDE_TRY(kde_dimconv_projective_to_real_depth(&h->conv, n, h->p.ERS->refined_depth.p, h->edge_points.p, stream));
     // :65-170 on the device: per-cluster plane of the labelled cloud (no D2H / host PCA / H2D)
     hipStream_t s = as_stream(stream);
-    KDE_TRY(launch_spdsr_cluster_planes(h->p.width, h->p.height, h->nclusters, h->p.ERS->labels_a.p, h->edge_points.p,
+    KDE_TRY(launch_spdsr_cluster_planes(h->p.width, h->p.height, n, h->nclusters, h->p.ERS->labels_a.p, h->edge_points.p,
                                         h->sums.p, h->cov.p, h->cluster_nd.p, s));
     // Projector->PlaneProjection(ClusterND_Device, refined labels, EdgeEnhanced3DPoints_Device) (:190)
-    return launch_spdsr_plane_projection(h->p.width, h->p.height, h->nclusters, h->cluster_nd.p, h->p.ERS->labels_a.p,
+    h->n_last = n;
+    return launch_spdsr_plane_projection(h->p.width, h->p.height, n, h->nclusters, h->cluster_nd.p, h->p.ERS->labels_a.p,
                                          h->edge_points.p, h->nxy.p, h->plane_fitted.p, h->opt_a.p, h->opt_b.p, 20,
                                          &h->optimized, s);
+}
+
+extern "C" int kde_spdsr_process(kde_spdsr* h, const float* depth_dev, const kde_float3* points_dev, const uint8_t* bgr_dev, void* stream)
+{
+    return kde_spdsr_process_batch(h, 1, depth_dev, points_dev, bgr_dev, stream);
 }
 
 extern "C" int kde_spdsr_refined_depth_device(kde_spdsr* h, float** out)
@@ -986,9 +1099,10 @@ extern "C" int kde_spdsr_optimized_points_host(kde_spdsr* h, void* stream, const
 {
     KDE_REQUIRE(h && out, "kde_spdsr_optimized_points_host: null argument");
     KDE_REQUIRE(h->optimized, "getOptimizedPoints: Process has not run yet");
+    KDE_ON_DEVICE(h->p.SP, "kde_spdsr_optimized_points_host");
     const size_t px = (size_t)h->p.width * h->p.height;
-    KDE_TRY(h->optimized_host.ensure(px));
-    KDE_HIP_TRY(hipMemcpyAsync(h->optimized_host.p, h->optimized, px * sizeof(kde_float3), hipMemcpyDeviceToHost, as_stream(stream)));
+    KDE_TRY(h->optimized_host.ensure(px * h->p.max_batch));
+    KDE_HIP_TRY(hipMemcpyAsync(h->optimized_host.p, h->optimized, px * h->n_last * sizeof(kde_float3), hipMemcpyDeviceToHost, as_stream(stream)));
     KDE_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     *out = h->optimized_host.p;
     return KDE_OK;

@@ -182,34 +182,36 @@ int launch_buf_update(kde_weighted_d* buf, const float* d, size_t n, int n_frame
 struct DaspGeom {
     int width, height, rows, cols, wx, wy;
 };
-int launch_dasp_sample(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
+// n = frames of a batch (per-frame colour / cloud / cluster tables / outputs, back to back); the single-frame forms take n = 1
+int launch_dasp_sample(const DaspGeom& g, int n, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
                        kde_float3* centers, hipStream_t s);
 int launch_dasp_calc_ld(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld,
                         const kde_superpixel* mean, const kde_float3* centers, int32_t* labels, float color_sigma,
                         float spatial_sigma, float depth_sigma, bool first, hipStream_t s);
-int launch_dasp_calc_ld_dual(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld_a,
+int launch_dasp_calc_ld_dual(const DaspGeom& g, int n, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld_a,
                              const kde_superpixel* mean_a, const kde_float3* centers_a, int32_t* labels_a,
                              const float sig_a[3], kde_label_distance* ld_b, const kde_superpixel* mean_b,
-                             const kde_float3* centers_b, int32_t* labels_b, const float sig_b[3], bool first, hipStream_t s);
+                             const kde_float3* centers_b, int32_t* labels_b, const float sig_b[3], bool first, bool write_ld,
+                             hipStream_t s);
 int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const int32_t* labels,
                         kde_superpixel* mean, kde_float3* centers, const float* intr_dev, hipStream_t s);
-int launch_dasp_analyze_dual(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const int32_t* labels_a,
+int launch_dasp_analyze_dual(const DaspGeom& g, int n, const uint8_t* bgr, const kde_float3* pts, const int32_t* labels_a,
                              kde_superpixel* mean_a, kde_float3* centers_a, const int32_t* labels_b, kde_superpixel* mean_b,
                              kde_float3* centers_b, const float* intr_dev, hipStream_t s);
 
 int launch_ers_edge_phase(int width, int height, int dir, int window, const int32_t* color_labels, const int32_t* l0,
                           const float* d0, int32_t* l1, float* d1, hipStream_t s);
-int launch_ers_edge_refining(int width, int height, int window, const int32_t* color_labels, const int32_t* l0,
+int launch_ers_edge_refining(int width, int height, int n, int window, const int32_t* color_labels, const int32_t* l0,
                              const float* d0, int32_t* scratch_l, float* scratch_d, int32_t* l2, float* d2, bool two_launches,
                              hipStream_t s);
-int launch_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr, const int32_t* labels,
+int launch_ers_enhance(int width, int height, int n, const float* rd, const uint8_t* bgr, const int32_t* labels,
                        const float* s_eff, const float* table_host, int window, float color_sigma, float depth_sigma,
                        float exp_zero, float* out, int variant, hipStream_t s);
 
 int launch_spdsr_init_normalized(const Camera& c, float* nxy, hipStream_t s);
-int launch_spdsr_cluster_planes(int width, int height, int nclusters, const int32_t* labels, const kde_float3* pts,
+int launch_spdsr_cluster_planes(int width, int height, int n, int nclusters, const int32_t* labels, const kde_float3* pts,
                                 double* sums, double* cov, float* nd, hipStream_t s);
-int launch_spdsr_plane_projection(int width, int height, int nclusters, const float* nd, const int32_t* labels,
+int launch_spdsr_plane_projection(int width, int height, int n, int nclusters, const float* nd, const int32_t* labels,
                                   const kde_float3* pts, const float* nxy, kde_float3* plane_fitted, kde_float3* opt_a,
                                   kde_float3* opt_b, int sweeps, kde_float3** result, hipStream_t s);
 

@@ -28,6 +28,13 @@ __global__ __launch_bounds__(kThreads) void cluster_moments_kernel(int npix, int
     constexpr int NV = COV ? 6 : 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* acc = reinterpret_cast<double*>(smem);
+    {   // blockIdx.y = frame of a batch: own labels, cloud and moment tables
+        const size_t f = blockIdx.y;
+        labels += f * npix;
+        pts += f * npix;
+        sums += f * nclusters * 4;
+        cov += f * nclusters * 6;
+    }
     if (use_lds) {
         for (int i = threadIdx.x; i < nclusters * NV; i += kThreads) acc[i] = 0.0;
         __syncthreads();
@@ -136,6 +143,9 @@ __global__ __launch_bounds__(64) void cluster_planes_kernel(int nclusters, const
 {
     const int l = blockIdx.x * 64 + threadIdx.x;
     if (l >= nclusters) return;
+    sums += (size_t)blockIdx.y * nclusters * 4;        // blockIdx.y = frame of a batch
+    cov += (size_t)blockIdx.y * nclusters * 6;
+    nd += (size_t)blockIdx.y * nclusters;
     const double cnt = sums[l * 4];
     if (cnt >= 3.0) {
         double A[3][3] = {{cov[l * 6] / cnt, cov[l * 6 + 1] / cnt, cov[l * 6 + 2] / cnt},
@@ -182,6 +192,10 @@ __global__ __launch_bounds__(kThreads) void set_pseudo_depth_kernel(int npix, in
 {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= npix) return;
+    {   // blockIdx.y = frame of a batch (the normalized rays nxy belong to the camera and are shared)
+        const size_t f = blockIdx.y;
+        nd += f * nclusters; labels += f * npix; pts += f * npix; plane_fitted += f * npix; z0 += f * npix; pfz += f * npix;
+    }
     const int l = labels[i];
     const kde_float3 p = pts[i];
     kde_float3 pf = p;
@@ -226,6 +240,10 @@ __global__ __launch_bounds__(kSwBX* kSwBY) void mrf_sweep_kernel(int width, int 
 {
     constexpr int R = 2, WIN = 5, HALF = 2, TW = kSwBX * 2, TH = kSwBY, LW = TW + 2 * R, LH = TH + 2 * R;
     __shared__ __attribute__((aligned(8))) float sz[LH * LW];
+    {   // blockIdx.z = frame of a batch
+        const size_t fpx = (size_t)blockIdx.z * width * height;
+        zin += fpx; pfz += fpx; zout += fpx;
+    }
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int tx = threadIdx.x % kSwBX, ty = threadIdx.x / kSwBX;
     const int x = x0 + 2 * tx, y = y0 + ty;
@@ -299,6 +317,10 @@ __global__ __launch_bounds__(kThreads) void mrf_expand_kernel(int npix, const fl
 {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= npix) return;
+    {
+        const size_t f = blockIdx.y;                    // frame of a batch
+        zfinal += f * npix; pts += f * npix; out += f * npix;
+    }
     const float zs = zfinal[i];
     kde_float3 o = pts[i];
     if (zs < 0.0f) {
@@ -321,45 +343,47 @@ int launch_spdsr_init_normalized(const Camera& c, float* nxy, hipStream_t s)
     return KDE_OK;
 }
 
-int launch_spdsr_cluster_planes(int width, int height, int nclusters, const int32_t* labels, const kde_float3* pts,
+// n frames back to back (labels, cloud; sums / cov / nd hold one table per frame)
+int launch_spdsr_cluster_planes(int width, int height, int n, int nclusters, const int32_t* labels, const kde_float3* pts,
                                 double* sums, double* cov, float* nd, hipStream_t s)
 {
     const int npix = width * height;
-    KDE_HIP_TRY(hipMemsetAsync(sums, 0, (size_t)nclusters * 4 * sizeof(double), s));
-    KDE_HIP_TRY(hipMemsetAsync(cov, 0, (size_t)nclusters * 6 * sizeof(double), s));
+    KDE_HIP_TRY(hipMemsetAsync(sums, 0, (size_t)n * nclusters * 4 * sizeof(double), s));
+    KDE_HIP_TRY(hipMemsetAsync(cov, 0, (size_t)n * nclusters * 6 * sizeof(double), s));
     const int use_lds = nclusters <= kMaxLdsClusters;
     const int blocks = ceil_div(npix, kThreads * 8);
-    hipLaunchKernelGGL(cluster_moments_kernel<false>, dim3(blocks), dim3(kThreads), use_lds ? (size_t)nclusters * 4 * 8 : 0, s,
+    hipLaunchKernelGGL(cluster_moments_kernel<false>, dim3(blocks, n), dim3(kThreads), use_lds ? (size_t)nclusters * 4 * 8 : 0, s,
                        npix, nclusters, use_lds, labels, pts, sums, cov);
-    hipLaunchKernelGGL(cluster_moments_kernel<true>, dim3(blocks), dim3(kThreads), use_lds ? (size_t)nclusters * 6 * 8 : 0, s,
+    hipLaunchKernelGGL(cluster_moments_kernel<true>, dim3(blocks, n), dim3(kThreads), use_lds ? (size_t)nclusters * 6 * 8 : 0, s,
                        npix, nclusters, use_lds, labels, pts, sums, cov);
-    hipLaunchKernelGGL(cluster_planes_kernel, dim3(ceil_div(nclusters, 64)), dim3(64), 0, s, nclusters, sums, cov,
+    hipLaunchKernelGGL(cluster_planes_kernel, dim3(ceil_div(nclusters, 64), n), dim3(64), 0, s, nclusters, sums, cov,
                        reinterpret_cast<float4*>(nd));
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }
 
-int launch_spdsr_plane_projection(int width, int height, int nclusters, const float* nd, const int32_t* labels,
+int launch_spdsr_plane_projection(int width, int height, int n, int nclusters, const float* nd, const int32_t* labels,
                                   const kde_float3* pts, const float* nxy, kde_float3* plane_fitted, kde_float3* opt_a,
                                   kde_float3* opt_b, int sweeps, kde_float3** result, hipStream_t s)
 {
     const int npix = width * height;
-    // opt_b (12 B/px) is carved into the three compact planes of the sweeps: z ping, z pong, plane-fitted z
+    // opt_b (12 B/px per frame) is carved into the three compact planes of the sweeps: z ping, z pong, plane-fitted z
+    // (each n frames back to back)
     float* zping = reinterpret_cast<float*>(opt_b);
-    float* zpong = zping + npix;
-    float* pfz = zpong + npix;
-    hipLaunchKernelGGL(set_pseudo_depth_kernel, dim3(ceil_div(npix, kThreads)), dim3(kThreads), 0, s, npix, nclusters,
+    float* zpong = zping + (size_t)n * npix;
+    float* pfz = zpong + (size_t)n * npix;
+    hipLaunchKernelGGL(set_pseudo_depth_kernel, dim3(ceil_div(npix, kThreads), n), dim3(kThreads), 0, s, npix, nclusters,
                        reinterpret_cast<const float4*>(nd), labels, pts, reinterpret_cast<const float2*>(nxy), plane_fitted,
                        zping, pfz);
     float *in = zping, *out = zpong;
-    dim3 grid(ceil_div(width, kSwBX * 2), ceil_div(height, kSwBY));
+    dim3 grid(ceil_div(width, kSwBX * 2), ceil_div(height, kSwBY), n);
     for (int i = 0; i < sweeps; i++) {
         hipLaunchKernelGGL(mrf_sweep_kernel, grid, dim3(kSwBX * kSwBY), 0, s, width, height, in, pfz, out);
         float* t = in;
         in = out;
         out = t;
     }
-    hipLaunchKernelGGL(mrf_expand_kernel, dim3(ceil_div(npix, kThreads)), dim3(kThreads), 0, s, npix, in, pts,
+    hipLaunchKernelGGL(mrf_expand_kernel, dim3(ceil_div(npix, kThreads), n), dim3(kThreads), 0, s, npix, in, pts,
                        reinterpret_cast<const float2*>(nxy), opt_a);
     KDE_HIP_TRY(hipGetLastError());
     *result = opt_a;

@@ -180,6 +180,12 @@ class MarkovRandomField(_Handle):
         check(lib().kde_mrf_filtered_device(self._h, C.byref(p)))
         return _view(p.value, (self.Height, self.Width), torch.float32, self)
 
+    def getFiltered_Host(self) -> np.ndarray:
+        """MarkovRandomField.h:16"""
+        p = C.c_void_p()
+        check(lib().kde_mrf_filtered_host(self._h, _stream(), C.byref(p)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(self.Height, self.Width)).copy()
+
 
 class DimensionConvertor(_Handle):
     """DimensionConvertor/DimensionConvertor.h:152-171.  float3 buffers are float32 tensors [..., 3]."""
@@ -367,10 +373,27 @@ class EdgeRefinedSuperpixel(_Handle):
 class _PipelineBase(_Handle):
     _prefix = ""
 
-    def __init__(self, width: int, height: int):
+    def __init__(self, width: int, height: int, max_batch: int = 1):
         super().__init__()
-        self.Width, self.Height = width, height
-        check(getattr(lib(), f"{self._prefix}_create")(C.byref(self._h), width, height))
+        self.Width, self.Height, self.max_batch = width, height, max_batch
+        if max_batch == 1:
+            check(getattr(lib(), f"{self._prefix}_create")(C.byref(self._h), width, height))
+        else:
+            check(getattr(lib(), f"{self._prefix}_create_batch")(C.byref(self._h), width, height, max_batch))
+        self._n = 1
+
+    def process_batch(self, depth: torch.Tensor, points: torch.Tensor, color: torch.Tensor) -> None:
+        """n independent frames back to back ([n,H,W], [n,H,W,3], [n,H,W,3]); the getters then return n frames"""
+        n = depth.shape[0]
+        hw = (self.Height, self.Width)
+        _req(depth, torch.float32, (n,) + hw, "depth")
+        _req(points, torch.float32, (n,) + hw + (3,), "points")
+        _req(color, torch.uint8, (n,) + hw + (3,), "color")
+        check(getattr(lib(), f"{self._prefix}_process_batch")(self._h, n, depth.data_ptr(), points.data_ptr(), color.data_ptr(), _stream()))
+        self._n = n
+
+    def _lead(self):
+        return () if self._n == 1 else (self._n,)
 
     def SetParametor(self, rows: int, cols: int, intrinsic) -> None:
         k = _K9(intrinsic)
@@ -384,6 +407,7 @@ class _PipelineBase(_Handle):
         _req(color_device, torch.uint8, hw + (3,), "color_device")
         check(getattr(lib(), f"{self._prefix}_process")(self._h, depth_device.data_ptr(), points_device.data_ptr(),
                                                         color_device.data_ptr(), _stream()))
+        self._n = 1
 
     def _get(self, fn, shape, dtype):
         p = C.c_void_p()
@@ -391,15 +415,15 @@ class _PipelineBase(_Handle):
         return _view(p.value, shape, dtype, self)
 
     def getRefinedDepth_Device(self) -> torch.Tensor:
-        return self._get("refined_depth_device", (self.Height, self.Width), torch.float32)
+        return self._get("refined_depth_device", self._lead() + (self.Height, self.Width), torch.float32)
 
     def getRefinedLabels_Device(self) -> torch.Tensor:
-        return self._get("refined_labels_device", (self.Height, self.Width), torch.int32)
+        return self._get("refined_labels_device", self._lead() + (self.Height, self.Width), torch.int32)
 
     def getRefinedDepth_Host(self) -> np.ndarray:
         p = C.c_void_p()
         check(getattr(lib(), f"{self._prefix}_refined_depth_host")(self._h, _stream(), C.byref(p)))
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(self.Height, self.Width)).copy()
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=self._lead() + (self.Height, self.Width)).copy()
 
 
 class RegionGrowingBilateralFilter(_PipelineBase):
@@ -408,10 +432,10 @@ class RegionGrowingBilateralFilter(_PipelineBase):
     _prefix = "kde_rgbf"
 
     def getSPLabels_Device(self):
-        return self._get("sp_labels_device", (self.Height, self.Width), torch.int32)
+        return self._get("sp_labels_device", self._lead() + (self.Height, self.Width), torch.int32)
 
     def getDASPLabels_Device(self):
-        return self._get("dasp_labels_device", (self.Height, self.Width), torch.int32)
+        return self._get("dasp_labels_device", self._lead() + (self.Height, self.Width), torch.int32)
 
 
 class SPDepthSuperResolution(_PipelineBase):
@@ -420,18 +444,18 @@ class SPDepthSuperResolution(_PipelineBase):
     _prefix = "kde_spdsr"
 
     def getEdgeEnhanced3DPoints_Device(self):
-        return self._get("edge_enhanced_points_device", (self.Height, self.Width, 3), torch.float32)
+        return self._get("edge_enhanced_points_device", self._lead() + (self.Height, self.Width, 3), torch.float32)
 
     def getOptimizedPoints_Device(self):
-        return self._get("optimized_points_device", (self.Height, self.Width, 3), torch.float32)
+        return self._get("optimized_points_device", self._lead() + (self.Height, self.Width, 3), torch.float32)
 
     def getOptimizedPoints_Host(self) -> np.ndarray:
         p = C.c_void_p()
         check(lib().kde_spdsr_optimized_points_host(self._h, _stream(), C.byref(p)))
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(self.Height, self.Width, 3)).copy()
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=self._lead() + (self.Height, self.Width, 3)).copy()
 
     def getPlaneFitted3D_Device(self):
-        return self._get("plane_fitted_points_device", (self.Height, self.Width, 3), torch.float32)
+        return self._get("plane_fitted_points_device", self._lead() + (self.Height, self.Width, 3), torch.float32)
 
     def getClusterND_Device(self):
-        return self._get("cluster_nd_device", (self.sp_rows * self.sp_cols, 4), torch.float32)
+        return self._get("cluster_nd_device", self._lead() + (self.sp_rows * self.sp_cols, 4), torch.float32)

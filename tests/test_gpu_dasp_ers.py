@@ -455,3 +455,71 @@ def test_k7_tie_break_follows_the_reference_tree(torch_cuda, F, oracle, synth, s
         assert len(np.unique(labels)) > 3                                    # not a degenerate single label
     with pytest.raises(Exception):
         F.DepthAdaptiveSuperpixel(w, h).Segmentation(dev(torch_cuda, bgr), dev(torch_cuda, pts_as_f32(pts)), 0.0, 0.0, 0.0, 1)
+
+
+@pytest.mark.parametrize("size,n,grid", [((160, 120), 5, (6, 8)), ((203, 77), 3, (5, 7)), ((640, 480), 4, (15, 20))])
+def test_rgbf_batch_is_bit_identical_to_single_frame_calls(torch_cuda, F, oracle, synth, size, n, grid):
+    """kde_rgbf_process_batch: every kernel of the chain takes the whole batch per launch; each frame's
+    SP / DASP / refined labels and refined depth equal its single-frame Process to the bit, in any batch position."""
+    w, h = size
+    bgr, depth = synth.make_batch(700, n, w, h)
+    K = synth.intrinsics(w, h)
+    t = torch_cuda
+    pts = np.stack([pts_as_f32(oracle.p2r_depth(depth[f], K)) for f in range(n)])
+    rgb = F.RegionGrowingBilateralFilter(w, h, max_batch=n)
+    rgb.SetParametor(grid[0], grid[1], K)
+    rgb.process_batch(dev(t, depth), dev(t, pts), dev(t, bgr))
+    got = {k: host(getattr(rgb, g)()).copy() for k, g in (("sp", "getSPLabels_Device"), ("da", "getDASPLabels_Device"),
+                                                           ("rl", "getRefinedLabels_Device"), ("rd", "getRefinedDepth_Device"))}
+    assert got["rd"].shape == (n, h, w)
+    rg1 = F.RegionGrowingBilateralFilter(w, h)
+    rg1.SetParametor(grid[0], grid[1], K)
+    for f in range(n):
+        rg1.Process(dev(t, depth[f]), dev(t, pts[f]), dev(t, bgr[f]))
+        assert np.array_equal(host(rg1.getSPLabels_Device()), got["sp"][f])
+        assert np.array_equal(host(rg1.getDASPLabels_Device()), got["da"][f])
+        assert np.array_equal(host(rg1.getRefinedLabels_Device()), got["rl"][f])
+        assert np.array_equal(host(rg1.getRefinedDepth_Device()).view(np.uint32), got["rd"][f].view(np.uint32))
+    assert np.array_equal(rgb.getRefinedDepth_Host().view(np.uint32), got["rd"].view(np.uint32))      # host getter: n frames
+    # a shorter batch on the same object, in another order: frames are independent units
+    perm = list(range(n - 1))[::-1]
+    rgb.process_batch(dev(t, depth[perm]), dev(t, pts[perm]), dev(t, bgr[perm]))
+    assert np.array_equal(host(rgb.getRefinedDepth_Device()).view(np.uint32), got["rd"][perm].view(np.uint32))
+    # and against the oracle (frame 0): labels exact, depth stage-wise
+    ref = oracle.rgbf_process(depth[0], oracle.p2r_depth(depth[0], K), bgr[0], grid[0], grid[1], K)
+    assert np.array_equal(got["rl"][0], ref["refined_labels"])
+    assert_k10_stagewise(ref["sp_labels"], ref["dasp_labels"], depth[0], bgr[0], got["rd"][0], what=f"RGBF batch frame 0 {w}x{h}")
+    from kinectdepthmapenhancement_amd import KdeError
+    with pytest.raises(KdeError):
+        rgb.process_batch(dev(t, np.concatenate([depth, depth])), dev(t, np.concatenate([pts, pts])), dev(t, np.concatenate([bgr, bgr])))
+
+
+def test_spdsr_batch_matches_single_frame_calls(torch_cuda, F, oracle, synth):
+    """kde_spdsr_process_batch: head (5 assignment iterations, ERS, back-projection) bit-identical per frame; the tail's
+    plane fit sums double-precision moments with atomics (order not fixed), so planes / optimised points agree to 1e-4"""
+    w, h, n = 160, 120, 3
+    bgr, depth = synth.make_batch(720, n, w, h)
+    K = synth.intrinsics(w, h)
+    t = torch_cuda
+    pts = np.stack([pts_as_f32(oracle.p2r_depth(depth[f], K)) for f in range(n)])
+    srb = F.SPDepthSuperResolution(w, h, max_batch=n)
+    srb.SetParametor(6, 8, K)
+    srb.process_batch(dev(t, depth), dev(t, pts), dev(t, bgr))
+    rl, rd = host(srb.getRefinedLabels_Device()).copy(), host(srb.getRefinedDepth_Device()).copy()
+    ep, nd = host(srb.getEdgeEnhanced3DPoints_Device()).copy(), host(srb.getClusterND_Device()).copy()
+    opt = host(srb.getOptimizedPoints_Device()).copy()
+    assert nd.shape == (n, 48, 4) and opt.shape == (n, h, w, 3)
+    for f in range(n):
+        # a fresh object per frame: a cluster without a plane keeps the distance its ClusterND slot held before
+        # (SPDepthSuperResolution.cpp:139-142 leaves the pinned entry alone), and every slot of the batch has its own table
+        sr1 = F.SPDepthSuperResolution(w, h)
+        sr1.SetParametor(6, 8, K)
+        sr1.Process(dev(t, depth[f]), dev(t, pts[f]), dev(t, bgr[f]))
+        assert np.array_equal(host(sr1.getRefinedLabels_Device()), rl[f])
+        assert np.array_equal(host(sr1.getRefinedDepth_Device()).view(np.uint32), rd[f].view(np.uint32))
+        assert np.array_equal(host(sr1.getEdgeEnhanced3DPoints_Device()).view(np.uint32), ep[f].view(np.uint32))
+        assert np.allclose(host(sr1.getClusterND_Device()), nd[f], rtol=2e-5, atol=2e-6)
+        o1 = host(sr1.getOptimizedPoints_Device())
+        fin = np.isfinite(o1).all(-1) & np.isfinite(opt[f]).all(-1)
+        assert np.array_equal(np.isfinite(o1), np.isfinite(opt[f])) and np.allclose(o1[fin], opt[f][fin], rtol=1e-4, atol=1e-2)
+    assert np.array_equal(srb.getOptimizedPoints_Host(), opt, equal_nan=True)

@@ -299,7 +299,9 @@ def test_rule_elision_bodies_all_match_the_oracle(torch_cuda, F, oracle, win):
         forced, _, bodies_forced = stage.jbf_stage_run(p, depth[None], bgr[None], v, force_full_rules=True)
         assert stage.bits_equal(forced[0], got), f"variant {nm}: forcing the full-rule body changed the output"
         assert bodies_forced[3] == bodies[:4].sum() and bodies_forced[:3].sum() == 0
-        if win >= 15:
+        if "noelide" in nm:
+            assert bodies[3] == bodies[:4].sum() and bodies[3] > 0, bodies[:4]                           # the full-rule body everywhere
+        elif win >= 15:
             assert bodies[3] > 0 and bodies[1] == 0 and bodies[2] == 0, bodies[:4]                       # {none, both} only
             assert bodies[0] > 0 or v != -1, bodies[:4]        # (the 128-pixel-wide tiles of some variants all straddle an edge here)
         else:
@@ -345,6 +347,12 @@ def test_mrf_sibling_filter(torch_cuda, F, oracle, frame):
     mrf = F.MarkovRandomField(320, 240)
     mrf.Process(dev(torch_cuda, depth), dev(torch_cuda, bgr))
     assert_mrf_close(host(mrf.getFiltered_Device()), oracle.mrf_kernel(depth, bgr), "MRF")
+    # float* getFiltered_Host() (MarkovRandomField.h:16): the object's own Filtered_Device, never a caller's buffer
+    assert np.array_equal(mrf.getFiltered_Host(), host(mrf.getFiltered_Device()))
+    own = mrf.getFiltered_Host().copy()
+    big = torch_cuda.empty((2, 240, 320), dtype=torch_cuda.float32, device="cuda")
+    mrf.process_batch(dev(torch_cuda, np.stack([depth, depth * 0.5])), dev(torch_cuda, np.stack([bgr, bgr])), big)   # caller-owned output
+    assert np.array_equal(mrf.getFiltered_Host(), own)
 
 
 @pytest.mark.parametrize("cfg", [

@@ -22,8 +22,7 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(PATH):
-            subprocess.check_call(["make", "-C", _HERE, "-s", "-j8", "libkde_hip_stage.so"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-j8", "libkde_hip_stage.so"])     # no-op when up to date
         from kinectdepthmapenhancement_amd import _native
         l = C.CDLL(PATH)
         for name, (res, args) in _native.SIGNATURES.items():
