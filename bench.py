@@ -466,7 +466,7 @@ def side_measurements(torch, filters, synth, args):
         guide = torch.empty_like(col)
         pre.presmooth_batch(col, guide)
         js = {}
-        for vname in ("auto", "w11-pk2-16x16-false-v1-noelide"):
+        for vname in ("auto", "w11-pk2-16x16-false-v4-noelide"):
             if vname != "auto" and vname not in names:
                 continue
             j = filters.JointBilateralFilter(640, 480, p11, max_batch=n64)
@@ -546,6 +546,14 @@ def side_measurements(torch, filters, synth, args):
 
     ms = timed(chain)
     out["fhd_full_chain_config5"] = {"ms_per_frame": ms, "mpix_s": W * H / ms / 1e3, "rows": 15, "cols": 20}
+    # the same chain on a BATCH of frames (north_star's unit): every stage takes the whole batch per launch
+    # (kde_jbf_process_batch, kde_rgbf_process_batch), next to the same frames pushed through the single-frame calls
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_chain_batch", os.path.join(ROOT, "tools", "bench_chain_batch.py"))
+    bcb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bcb)
+    out["vga_chain_batch64"] = bcb.run(torch, filters, synth, 640, 480, 64, 6)
+    out["fhd_chain_batch8"] = bcb.run(torch, filters, synth, 1920, 1080, 8, 6)
     db = d[None].repeat(32, 1, 1).contiguous()
     pb = torch.empty((32, H, W, 3), dtype=torch.float32, device="cuda")
     ms = timed(lambda: conv.projectiveToReal(db, pb))

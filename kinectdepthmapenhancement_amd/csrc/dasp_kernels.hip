@@ -118,7 +118,7 @@ struct ClusterRec {   // LDS copy of one cluster: 32 B
     float r, g, b;
     float x, y;           // pixel coordinates as floats (exact below 2^24): offsets to a pixel are one v_sub_f32 each
     float cz;
-    int pad0, pad1;
+    int xi, yi;           // the same coordinates as the reference holds them: used when one does not fit a float (see big)
 };
 
 constexpr int kMaxLdsClusters = 2048;   // 64 KiB of LDS
@@ -170,7 +170,16 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
             sets.s[n].centers += fk;
         }
     }
+    // analyzeClusters keeps a projected centre whose row lies BELOW the image (its test reads pixel.y <= height, .cu:549),
+    // so mean.y can be any int above the height, INT_MAX included.  (float)(y - mean.y), which the reference forms
+    // (.cu:213), equals (float)y - (float)mean.y only while both fit a float exactly: a table that holds such a
+    // coordinate (|v| >= 2^24) switches the workgroup to the integer subtraction and the library sqrtf.
+    __shared__ int s_big;
+    bool big = !USE_LDS;              // the table-in-global form always subtracts integers
     if (USE_LDS) {
+        if (threadIdx.x == 0) s_big = 0;
+        __syncthreads();
+        bool mine = false;
 #pragma unroll
         for (int n = 0; n < NTAB; n++)
             for (int i = threadIdx.x; i < nclusters; i += 256) {
@@ -182,10 +191,14 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
                 r.x = (float)m.x;
                 r.y = (float)m.y;
                 r.cz = sets.s[n].centers[i].z;
-                r.pad0 = r.pad1 = 0;
+                r.xi = m.x;
+                r.yi = m.y;
+                mine |= m.x >= (1 << 24) || m.x <= -(1 << 24) || m.y >= (1 << 24) || m.y <= -(1 << 24);
                 recs[n * nclusters + i] = r;
             }
+        if (mine) s_big = 1;
         __syncthreads();
+        big = s_big != 0;             // workgroup-uniform
     }
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -198,18 +211,25 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
     // the three distances of candidate t against cluster table n (.cu:196-217)
     auto candidate = [&](int n, int id, float& color_distance, float& spatial_distance, float& depth_distance) {
         float mr, mg, mb, cz, mx, my;
+        int mxi, myi;
         if (USE_LDS) {
             const ClusterRec r = recs[n * nclusters + id];
-            mr = r.r; mg = r.g; mb = r.b; mx = r.x; my = r.y; cz = r.cz;
+            mr = r.r; mg = r.g; mb = r.b; mx = r.x; my = r.y; cz = r.cz; mxi = r.xi; myi = r.yi;
         } else {
             const kde_superpixel m = sets.s[n].mean[id];
-            mr = (float)m.r; mg = (float)m.g; mb = (float)m.b; mx = (float)m.x; my = (float)m.y;
+            mr = (float)m.r; mg = (float)m.g; mb = (float)m.b; mx = (float)m.x; my = (float)m.y; mxi = m.x; myi = m.y;
             cz = sets.s[n].centers[id].z;
         }
         const float e0 = c0 - mr, e1 = c1 - mg, e2 = c2 - mb;
         color_distance = e0 * e0 + e1 * e1 + e2 * e2;
-        const float px = xf - mx, py = yf - my;       // = (float)(x - mx): integers below 2^24
-        spatial_distance = sqrt_int24(px * px + py * py) * win2;
+        if (big) {
+            // (x - mean.x wraps for mean.x near INT_MIN exactly as the reference's int subtraction does on the GPU)
+            const float px = (float)(int)((unsigned)x - (unsigned)mxi), py = (float)(int)((unsigned)y - (unsigned)myi);
+            spatial_distance = sqrtf(px * px + py * py) * win2;
+        } else {
+            const float px = xf - mx, py = yf - my;       // = (float)(x - mx): integers below 2^24
+            spatial_distance = sqrt_int24(px * px + py * py) * win2;
+        }
         depth_distance = 0.0f;
         if (z > 50.0f && cz > 50.0f) depth_distance = fabsf(z - cz);
     };
@@ -267,15 +287,16 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
                 }
                 continue;
             }
-            float mx, my;
-            if (USE_LDS) {
-                mx = recs[tab * nclusters + id].x;
-                my = recs[tab * nclusters + id].y;
+            float px, py;
+            if (USE_LDS && !big) {
+                px = xf - recs[tab * nclusters + id].x;
+                py = yf - recs[tab * nclusters + id].y;
             } else {
-                mx = (float)sets.s[tab].mean[id].x;
-                my = (float)sets.s[tab].mean[id].y;
+                const int mxi = USE_LDS ? recs[tab * nclusters + id].xi : sets.s[tab].mean[id].x;
+                const int myi = USE_LDS ? recs[tab * nclusters + id].yi : sets.s[tab].mean[id].y;
+                px = (float)(int)((unsigned)x - (unsigned)mxi);
+                py = (float)(int)((unsigned)y - (unsigned)myi);
             }
-            const float px = xf - mx, py = yf - my;
             const float n2 = px * px + py * py;
             const bool need = !(n2 > thr_any);       // some segmenter of this pass may still need the candidate
             if (__builtin_amdgcn_ballot_w64(need) == 0) continue;              // nobody in the wavefront needs it
@@ -383,12 +404,13 @@ __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const
     // slower: the kernel is bound by the strided gathers of the matched pixels, one cache line per lane.)
     constexpr int CH = 8;
     const size_t last_pix = (size_t)g.width * g.height - 1;    // its 4-byte colour read would leave the buffer
-    const int ax0 = m0.x + (tx - 8) * rpx, ay0 = m0.y + (ty - 8) * rpy;
+    // 32-bit wrapping adds, as the reference's: a centre kept below the image (y up to INT_MAX) scans rows that wrap to negative
+    const int ax0 = (int)((unsigned)m0.x + (unsigned)((tx - 8) * rpx)), ay0 = (int)((unsigned)m0.y + (unsigned)((ty - 8) * rpy));
     // rows of the sub-window in the reference's order, CH positions at a time; labels are fetched four positions per
     // 16-byte load (the kernel is bound by the NUMBER of per-lane cache-line accesses of its strided gathers, so
     // bytes per access is what counts)
     for (int yy = 0; yy < rpy; yy++) {
-      const int ary = ay0 + yy;
+      const int ary = (int)((unsigned)ay0 + (unsigned)yy);
       const bool row_in = ary >= 0 && ary < g.height;
       for (int xc = 0; xc < rpx; xc += CH) {
         bool hit[CH];
@@ -396,7 +418,7 @@ __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const
         int px_[CH], py_[CH];
 #pragma unroll
         for (int k = 0; k < CH; k += 4) {
-            const int arx = ax0 + xc + k;
+            const int arx = (int)((unsigned)ax0 + (unsigned)(xc + k));
             bool in[4];
             bool all_in = true;
 #pragma unroll

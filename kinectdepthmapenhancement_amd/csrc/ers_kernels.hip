@@ -776,9 +776,11 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
         const float dmin = __uint_as_float(s_rng[0]), dmax = __uint_as_float(s_rng[1]);
         if (s_rng[1] >= s_rng[0]) {
             // valid depths and every average of them lie in [dmin, dmax]: |d - avg| * sd <= span for every valid tap
-            const float span = (dmax - dmin) * a.sd * 1.001f;
+            // (+ slack: the float32 average can leave [dmin, dmax] by the rounding of its sums, (taps + 8) / 2 ulps of dmax)
+            const float slack = dmax * (float)(49 + 8) * 0x1p-24f;
+            const float span = ((dmax - dmin) * 1.001f + slack) * a.sd;
             tile_no_drule = span * span < a.t2_skip * 0.999f;
-            const float ab = 5.0f * (dmax - dmin) / (dmin * dmin) * 1.001f;
+            const float ab = 5.0f * ((dmax - dmin) + slack) / (dmin * dmin) * 1.001f;
             const float denb = 2.0f * (ab * ab);
             const float tl = a.tinv[a.kfree > 0 ? a.kfree - 1 : 0];
             tile_small_a = a.kfree < 50 && (denb == 0.0f || (1.0f / denb >= a.exp_zero * 1.001f && 1.4426950408889634f / denb >= tl * 1.001f));

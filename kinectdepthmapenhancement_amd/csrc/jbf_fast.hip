@@ -284,12 +284,17 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     //  slower than unaligned pair reads because of the extra, nearly empty tile column it costs)
     constexpr int S1 = 0;
     constexpr int RA = !VL ? R : ((R + 3) / 4 * 4);
-    constexpr bool ALIGNED = ((RA - R) % 2) == 0;     // row segments start on an even LDS column
-    constexpr int P = VL ? (RA + TW + R + 3) / 4 * 4 : (TW + 2 * R);   // row pitch in dwords
-    constexpr int G = P / 4;                          // 4-pixel groups per row
+    // SH: with the vector loader an odd RA - R (radii 5, 9: windows 11, 19) would start every thread's row segment on an odd
+    // LDS column and turn the ds_read_b64 of the pass loops into pairs of ds_read_b32 (measured 5-19 % slower in r02).
+    // The staged rows are therefore shifted right by one dword: the global loads stay 16-byte / 12-byte groups aligned in
+    // the image, the LDS writes of a group become four single dwords, and the pass loops keep their 64-bit reads.
+    constexpr int SH = VL ? ((RA - R) & 1) : 0;
+    constexpr bool ALIGNED = ((RA - R + SH) % 2) == 0;     // row segments start on an even LDS column
+    constexpr int G = (RA + TW + R + 3) / 4;          // 4-pixel groups per staged row (vector loader)
+    constexpr int P = VL ? (SH + 4 * G + 1) / 2 * 2 : (TW + 2 * R);   // row pitch in dwords (even; a multiple of 4 when SH == 0)
     constexpr int SEGP = NP + R;                      // aligned pairs in the row segment of a thread
     constexpr int HALF = (WIN - 1) / 2;
-    static_assert(RA >= R && P % 2 == 0 && (!VL || ((RA + S1) % 4 == 0 && TW % 4 == 0)), "tile geometry");
+    static_assert(RA >= R && P % 2 == 0 && (!VL || ((RA + S1) % 4 == 0 && TW % 4 == 0 && (SH != 0 || P % 4 == 0))), "tile geometry");
     __shared__ __attribute__((aligned(16))) float s_d[LH * P];
     __shared__ __attribute__((aligned(16))) uint32_t s_c[LH * P];
     __shared__ __attribute__((aligned(16))) uint32_t s_n[LH * P];
@@ -396,10 +401,19 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
             nn[k] = (kMagic + kOff) - dot4(c[k], c[k], 0);
             stat(d[k], c[k], gy >= 0 && gy < a.height && gx + k >= 0 && gx + k < a.width);
         }
-        const int li = ly * P + 4 * gi;
-        *reinterpret_cast<float4*>(&s_d[li]) = make_float4(d[0], d[1], d[2], d[3]);
-        *reinterpret_cast<uint4*>(&s_c[li]) = make_uint4(c[0], c[1], c[2], c[3]);
-        *reinterpret_cast<uint4*>(&s_n[li]) = make_uint4(nn[0], nn[1], nn[2], nn[3]);
+        const int li = ly * P + 4 * gi + SH;
+        if constexpr (SH == 0) {
+            *reinterpret_cast<float4*>(&s_d[li]) = make_float4(d[0], d[1], d[2], d[3]);
+            *reinterpret_cast<uint4*>(&s_c[li]) = make_uint4(c[0], c[1], c[2], c[3]);
+            *reinterpret_cast<uint4*>(&s_n[li]) = make_uint4(nn[0], nn[1], nn[2], nn[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                s_d[li + k] = d[k];
+                s_c[li + k] = c[k];
+                s_n[li + k] = nn[k];
+            }
+        }
     }
     if (ELIDE) {   // wavefront reduction (xor butterflies), then one LDS atomic per wavefront and statistic
         uint32_t v[8] = {st_dmin, st_dmax, st_cmin[0], st_cmax[0], st_cmin[1], st_cmax[1], st_cmin[2], st_cmax[2]};
@@ -432,7 +446,11 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         const int rb = (int)s_stat[3] - (int)s_stat[2], rg = (int)s_stat[5] - (int)s_stat[4], rr = (int)s_stat[7] - (int)s_stat[6];
         if (s_stat[3] >= s_stat[2]) tile_c = CSKIP && (rb * rb + rg * rg + rr * rr >= a.cd_skip);
         const float range = __uint_as_float(s_stat[1]) - __uint_as_float(s_stat[0]);       // -inf when no valid depth was staged
-        tile_d = !(range * a.sd * 1.0001f < a.t_skip);
+        // avg_p is a float32 quotient of float32 sums: it can leave [dmin, dmax] by the rounding of those sums, at most
+        // about (taps + 8) / 2 ulps of dmax -- an absolute slack that a purely relative margin on the range does not cover
+        // when the depths are large and sigma_d is small (1e4 mm at sigma_d = 1 mm)
+        const float slack = __uint_as_float(s_stat[1]) * (float)(WIN * WIN + 8) * 0x1p-24f;
+        tile_d = !((range * 1.0001f + slack) * a.sd < a.t_skip);
     }
     KDE_STAGE(if (a.stage_force) { tile_c = CSKIP; tile_d = true; })
     KDE_STAGE(if (a.stage_counters && tid == 0) {
@@ -447,7 +465,7 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
     const int tx = tid % BX, ty = tid / BX;
     const int xb = x0 + tx * PX, y = y0 + ty;
     if (xb >= a.width || y >= a.height) return;
-    const int sx = RA - R + tx * PX;       // LDS column of this thread's first window column (even)
+    const int sx = SH + RA - R + tx * PX;  // LDS column of this thread's first window column (even)
 
     uint32_t cc[PX];
     f2 negC[NP];          // -(2^23 + 2^18 + |a|^2): F + negC = -cd exactly (integers < 2^24)
@@ -673,19 +691,21 @@ struct Variant {
 #define KS(WIN, NP, BX, BY, CACHE) \
     {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v1", WIN, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, false>}
 #define KN(WIN, NP, BX, BY, CACHE) \
-    {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v1-noelide", WIN, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, false, false>}
+    {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v4-noelide", WIN, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, true, false>}
 const Variant kVariants[] = {
     // the FIRST variant listed for a window is the built-in choice (interleaved A/B sweep on MI355X,
-    // profiles/r02_sweep_k1_variants.log); the others stay selectable for the tile sweep of BASELINE config 3
+    // profiles/r03_sweep_k1_variants.log); the others stay selectable for the tile sweep of BASELINE config 3.
+    // r03: the vector loader ("-v4": 16-byte depth + 12-byte colour loads, LDS rows shifted so that the pass loops keep
+    // their 64-bit reads) is the default at every window: 10.11 vs 10.17 ms at window 19, 1.102 vs 1.101 at window 11
     K(5, 1, 16, 16, true),  K(5, 1, 32, 8, true),   KS(5, 1, 16, 16, true),  K(5, 2, 32, 8, true),  K(5, 1, 32, 8, false),
     V(5, 2, 32, 8, true),   V(5, 1, 64, 4, true),
     K(7, 1, 16, 16, true),  K(7, 1, 32, 8, true),   KS(7, 1, 32, 8, true),  K(7, 1, 32, 8, false),  V(7, 1, 64, 4, true),
     // tiles (pixels) of BASELINE config 3's sweep: 64x16 / 32x16 / 64x8 / 128x8 with 4 or 2 pixels per thread (packed pairs),
     // and the scalar kernels at 2 and 1 pixels per thread (32x16, 32x8)
-    KS(11, 2, 16, 16, false), K(11, 2, 16, 16, false), KS(11, 1, 16, 16, false), K(11, 1, 16, 16, false), K(11, 1, 32, 8, false),
+    K(11, 2, 16, 16, false), KS(11, 2, 16, 16, false), KS(11, 1, 16, 16, false), K(11, 1, 16, 16, false), K(11, 1, 32, 8, false),
     KS(11, 1, 32, 8, false), KS(11, 2, 32, 8, false), V(11, 2, 16, 16, false), V(11, 1, 32, 8, false),
     KN(11, 2, 16, 16, false),      // the default without tile-level rule elision: the window's data-independent floor
-    KS(19, 1, 16, 16, false), KS(19, 2, 16, 16, false), K(19, 2, 16, 16, false), K(19, 1, 16, 16, false), K(19, 1, 32, 8, false),
+    K(19, 1, 16, 16, false), KS(19, 1, 16, 16, false), KS(19, 2, 16, 16, false), K(19, 2, 16, 16, false), K(19, 1, 32, 8, false),
     KS(19, 1, 32, 8, false), KS(19, 2, 32, 8, false), V(19, 2, 16, 16, false), V(19, 1, 32, 8, false),
     KN(19, 1, 16, 16, false),
 };

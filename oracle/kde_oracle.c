@@ -881,7 +881,8 @@ void okde_dasp_calculate_ld(int width, int height, int rows, int cols, const uin
                         float e1 = (float)c[1] - (float)mean[id].g;
                         float e2 = (float)c[2] - (float)mean[id].b;
                         float color_distance = e0 * e0 + e1 * e1 + e2 * e2;
-                        float px = (float)(x - mean[id].x), py = (float)(y - mean[id].y);
+                        /* int subtraction as on the GPU (wraps) */
+                        float px = (float)(int)((unsigned)x - (unsigned)mean[id].x), py = (float)(int)((unsigned)y - (unsigned)mean[id].y);
                         float spatial_distance = sqrtf(px * px + py * py) * win2;
                         float depth_distance = 0.0f;
                         if (z > 50.0f && centers[id].z > 50.0f) depth_distance = fabsf(z - centers[id].z);
@@ -931,8 +932,10 @@ void okde_dasp_analyze_clusters(int width, int height, int rows, int cols, const
                     float xf = 0.0f, yf = 0.0f, zf = 0.0f;
                     for (int yy = 0; yy < rpy; yy++) {
                         for (int xx = 0; xx < rpx; xx++) {
-                            const int arx = mx + (tx - 8) * rpx + xx;
-                            const int ary = my + (ty - 8) * rpy + yy;
+                            /* the GPU's 32-bit adds wrap: mean.y can be INT_MAX (a projected centre kept below the
+                             * image, :549), and INT_MAX + offset is then a negative row, i.e. outside the image */
+                            const int arx = (int)((unsigned)mx + (unsigned)((tx - 8) * rpx + xx));
+                            const int ary = (int)((unsigned)my + (unsigned)((ty - 8) * rpy + yy));
                             if (arx >= 0 && arx < width && ary >= 0 && ary < height) {
                                 const size_t q = (size_t)ary * width + arx;
                                 if (ld[q].l == cluster_id) {

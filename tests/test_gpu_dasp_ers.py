@@ -48,6 +48,30 @@ def test_dasp_segmentation_exact(torch_cuda, F, oracle, synth, frame, cfg):
     assert np.array_equal(host(d.getCentersDevice()), pts_as_f32(centers), equal_nan=True)
 
 
+def test_dasp_cluster_centre_kept_below_the_image(torch_cuda, F, oracle, synth, frame):
+    """analyzeClusters keeps a projected centre whose row lies below the image (pixel.y <= height [sic], .cu:549): mean.y can
+    be any int above the height, INT_MAX included (saturating float -> int).  calculateLD then forms (float)(y - mean.y),
+    which a float subtraction reproduces only below 2^24: such a table takes the integer path."""
+    w, h = 160, 120
+    bgr, depth, K, pts = _inputs(oracle, synth, frame, 15, w, h)
+    p = pts_as_f32(pts).copy()
+    p[20:50, 30:70] = (0.0, -1.0e9, 100.0)          # projects to column cx, row cy + 1e7 * fy (centroids mix with ordinary points: rows up to 1.4e9)
+    p[80:100, 100:140] = (0.0, -40000.0, 100.0)     # row cy + 400 * fy = 57 000: above the height, below 2^24
+    pv = np.ascontiguousarray(p).view(oracle.FLOAT3).reshape(h, w)
+    for sig in ((200.0, 40.0, 0.0), (100.0, 20.0, 200.0)):
+        labels, ld, mean, centers = oracle.dasp_segmentation(bgr, pv, 6, 8, K, *sig, 4)
+        assert (mean["y"] >= (1 << 24)).any() and ((mean["y"] > h) & (mean["y"] < (1 << 24))).any()
+        d = F.DepthAdaptiveSuperpixel(w, h)
+        d.SetParametor(6, 8, K)
+        d.Segmentation(dev(torch_cuda, bgr), dev(torch_cuda, p), *sig, 4)
+        assert np.array_equal(host(d.getLabelDevice()), labels)
+        gl = ld_records(d.getLDDevice())
+        assert np.array_equal(gl["l"], ld["l"]) and np.array_equal(gl["d"], ld["d"])
+        gm = mean_records(d.getMeanDataDevice())
+        for f in ("r", "g", "b", "x", "y", "size"):
+            assert np.array_equal(gm[f], mean[f]), f
+
+
 def test_dasp_geometry_guard(torch_cuda, F, synth):
     from kinectdepthmapenhancement_amd import KdeError
     d = F.DepthAdaptiveSuperpixel(64, 48)
