@@ -21,6 +21,13 @@ int kde_bench_copy(const void* src_dev, void* dst_dev, size_t bytes, void* strea
  * form (DepthAdaptiveSuperpixel.cu:213).  0 = ok. */
 int kde_test_sqrt_int24(uint32_t first, uint32_t n, float* out_dev, void* stream);
 
+/* out_dev[i] = fastdiv24(xs_dev[i], make_fastdiv24(d, max_dividend)) evaluated ON THE DEVICE with the very functions of
+ * csrc/kde_device_math.h (the division-by-multiplication of K1's tile map and K7's grid-cell arithmetic), so that a test
+ * can compare it with x / d -- including the fallback path (ok == 0: d or max_dividend >= 2^24).  m_sh_ok (host, 3 words,
+ * may be NULL) receives the magic number, the shift and the ok flag make_fastdiv24 chose.  0 = ok. */
+int kde_test_fastdiv24(uint32_t d, uint64_t max_dividend, uint32_t n, const uint32_t* xs_dev, uint32_t* out_dev,
+                       uint32_t* m_sh_ok, void* stream);
+
 /* ---- tools/hooks/libkde_hip_stage.so ------------------------------------------------------------------------------
  * The product library's own sources compiled with -DKDE_STAGE_HOOKS: every entry point of include/kde_hip.h (same
  * code, same flags) plus the one below.  It exists so that the parity tests can check K1 and K10 STAGE BY STAGE: the

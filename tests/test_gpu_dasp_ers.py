@@ -547,3 +547,49 @@ def test_spdsr_batch_matches_single_frame_calls(torch_cuda, F, oracle, synth):
         fin = np.isfinite(o1).all(-1) & np.isfinite(opt[f]).all(-1)
         assert np.array_equal(np.isfinite(o1), np.isfinite(opt[f])) and np.allclose(o1[fin], opt[f][fin], rtol=1e-4, atol=1e-2)
     assert np.array_equal(srb.getOptimizedPoints_Host(), opt, equal_nan=True)
+
+
+def test_fastdiv24_device_function_equals_integer_division(torch_cuda):
+    """tests/test_oracle_micro.py re-implements the magic-number formula in Python; this calls the real
+    make_fastdiv24 (host) + fastdiv24 (device) of csrc/kde_device_math.h through tools/hooks: every divisor a launcher can
+    form (tiles per frame, tiles per row, cell sizes, grid columns) at the edges of its dividend range, random pairs, and
+    the fallback (ok == 0: divisor or dividend bound >= 2^24), which must be a plain division."""
+    import ctypes
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("kde_hooks", os.path.join(ROOT, "tools", "hooks", "hooks.py"))
+    hooks = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hooks)
+    t = torch_cuda
+    rng = np.random.default_rng(3)
+    st = t.cuda.current_stream().cuda_stream
+
+    def probe(d, maxdiv, xs):
+        xs = np.asarray(xs, np.uint32)
+        x = t.from_numpy(xs.view(np.int32)).cuda()
+        out = t.empty_like(x)
+        info = (ctypes.c_uint32 * 3)()
+        assert hooks.lib().kde_test_fastdiv24(int(d), int(maxdiv), xs.size, x.data_ptr(), out.data_ptr(), info, st) == 0
+        return out.cpu().numpy().view(np.uint32), tuple(info)
+
+    divisors = sorted(set([1, 2, 3, 5, 7, 10, 20, 32, 40, 60, 63, 64, 65, 72, 96, 300, 1200, 4080, 8100, 65535, 65536, 65537,
+                           (1 << 23) - 1, 1 << 23, (1 << 24) - 1] + rng.integers(1, 1 << 24, 40).tolist()))
+    for d in divisors:
+        top = (1 << 24) - 1
+        xs = np.unique(np.concatenate([[0, 1, d - 1, d, d + 1, top - 1, top], (np.arange(1, 40) * d - 1) % (top + 1),
+                                       (np.arange(1, 40) * d) % (top + 1), rng.integers(0, top + 1, 4000)])).astype(np.uint32)
+        got, (m, sh, ok) = probe(d, top, xs)
+        assert ok == 1, d
+        assert np.array_equal(got, xs // np.uint32(d)), d
+    # exhaustive for a few divisors over the WHOLE 24-bit dividend range
+    allx = np.arange(1 << 24, dtype=np.uint32)
+    for d in (3, 40, 8100, 4079):
+        got, _ = probe(d, (1 << 24) - 1, allx)
+        assert np.array_equal(got, allx // np.uint32(d)), d
+    # fallback: the proven range is left -> ok == 0 and the result is the hardware division, for any 32-bit dividend
+    big = np.concatenate([[0, 1, (1 << 24), (1 << 31), 0xFFFFFFFF], rng.integers(0, 1 << 32, 4000, dtype=np.uint64)]).astype(np.uint32)
+    for d, maxdiv in ((7, 1 << 24), (40, 1 << 30), (1 << 24, (1 << 24) - 1), (3_000_000_000 % (1 << 32), 1 << 20)):
+        got, (m, sh, ok) = probe(d, maxdiv, big)
+        assert ok == 0, (d, maxdiv)
+        assert np.array_equal(got, big // np.uint32(d)), (d, maxdiv)

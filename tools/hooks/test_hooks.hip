@@ -23,7 +23,29 @@ __global__ __launch_bounds__(256) void sqrt_int24_probe_kernel(uint32_t first, u
     if (i < n) out[i] = kde::sqrt_int24((float)(first + i));
 }
 
+__global__ __launch_bounds__(256) void fastdiv24_probe_kernel(kde::FastDiv24 f, uint32_t n, const uint32_t* __restrict__ xs,
+                                                             uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] = kde::fastdiv24(xs[i], f);
+}
+
 }  // namespace
+
+extern "C" int kde_test_fastdiv24(uint32_t d, uint64_t max_dividend, uint32_t n, const uint32_t* xs_dev, uint32_t* out_dev,
+                                  uint32_t* m_sh_ok, void* stream)
+{
+    if (!xs_dev || !out_dev || d == 0) return 1;
+    const kde::FastDiv24 f = kde::make_fastdiv24(d, max_dividend);      // the host function the launchers call
+    if (m_sh_ok) {
+        m_sh_ok[0] = f.m;
+        m_sh_ok[1] = f.sh;
+        m_sh_ok[2] = f.ok;
+    }
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fastdiv24_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), f, n, xs_dev, out_dev);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
 
 extern "C" int kde_bench_copy(const void* src_dev, void* dst_dev, size_t bytes, void* stream)
 {

@@ -6,6 +6,8 @@
 #               -> pmc_bench.json (also copied to profiles/pmc_bench.json of the box copy so that the bench lines of
 #               this call quote the traffic / instruction counts of THIS build)
 #   pmc_chain   PMC passes over tools/bench_chain.py (K2, K6-K10), tools/bench_mrf.py and tools/bench_spdsr.py
+#   pmc_feeders PMC passes over tools/bench_feeders.py (Buffer2D::updateData over 128 distinct 1080p frames, projectiveToReal
+#               on 4.2 GB): HBM traffic of the streaming kernels on working sets far beyond the Infinity Cache
 #   stats       rocprofv3 --kernel-trace --stats over the default bench command, the chain and SPDSR
 #   bench       the plain bench line
 #   chain       tools/bench_chain.py at 1080p and 640x480, tools/bench_spdsr.py, tools/bench_mrf.py
@@ -15,7 +17,7 @@
 set -eo pipefail
 TAG=${1:-final}
 shift || true
-STEPS=${*:-pmc_bench pmc_chain stats bench chain sweep micro}
+STEPS=${*:-pmc_bench pmc_chain pmc_feeders stats bench chain sweep micro}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -68,6 +70,15 @@ for d in parts:
 json.dump(merged, open(f"{out}/pmc_chain_all.json", "w"), indent=1)
 PY
   ;;
+pmc_feeders)
+  pmc_passes pmc_feeders python3 tools/bench_feeders.py --iters 3 --wakeup-ms 0
+  # algorithmic bytes per launch: update (4 * 128 + 16) B/px, projectiveToReal 16 B/px x 128, copy 8 B/px x 128 (1920x1080)
+  echo '{"buf_update4": 1094860800, "p2r_depth": 4246732800, "copy_kernel": 2123366400}' > "$OUT/algo_feeders.json"
+  python3 tools/pmc_report.py --dir "$OUT/pmc_feeders" --out "$OUT/pmc_feeders.json" --command "python3 tools/bench_feeders.py --iters 3 --wakeup-ms 0" \
+      --algo "$OUT/algo_feeders.json" 2> "$OUT/pmc_feeders.summary"
+  python3 tools/bench_feeders.py > "$OUT/feeders.json" 2> "$OUT/feeders.err"
+  cat "$OUT/pmc_feeders.summary" "$OUT/feeders.json"
+  ;;
 stats)
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 bench.py --cpu-seconds 0 --no-verify > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/chain_stats" -o chain -- python3 tools/bench_chain.py > /dev/null 2> "$OUT/chain_stats.err"
@@ -88,7 +99,7 @@ chain)
   ;;
 sweep)
   {
-    python3 tools/sweep_jbf.py --width 1920 --height 1080 --frames 8 --window 19 --with-generic
+    python3 tools/sweep_jbf.py --width 1920 --height 1080 --frames 32 --window 19 --iters 2 --rounds 3 --with-generic     # config 3 as SURVEY 8(d) sizes it
     python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 19
     python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 11 --with-generic
     python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 7 --spatial-sigma 70 --color-sigma 50 --depth-sigma 20
