@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--share-device", action="store_true",
                     help="every rank uses cuda:0 (rehearsal of the N > 1 path on a one-GPU box; needs --backend gloo)")
     ap.add_argument("--first-frame", type=int, default=0, help="global index of the first frame (N = 1 runs of one shard of a larger batch)")
+    ap.add_argument("--dump-frames", default="",
+                    help="write this rank's input frames (all colour frames, then all depth frames, raw) for examples/shard_replay --frames-file")
     ap.add_argument("--dry-run", action="store_true",
                     help="everything but the GPU work: launch, process group, parameter broadcast, partition, reductions (CPU test of the N > 1 path)")
     return ap.parse_args()
@@ -351,6 +353,10 @@ def main():
             dist.destroy_process_group()
         return
     color, depth = make_inputs(synth, torch, first, count, W, H, args.distinct_frames)
+    if args.dump_frames and rank == 0:
+        with open(args.dump_frames, "wb") as f:
+            f.write(color.cpu().numpy().tobytes())
+            f.write(depth.cpu().numpy().tobytes())
     smooth = torch.empty_like(color)
     out = torch.empty_like(depth)
     jbf = filters.JointBilateralFilter(W, H, p, max_batch=count)

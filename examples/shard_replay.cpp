@@ -8,7 +8,14 @@
 // The reference uploads to a single device (main.cpp:160-163); this is the multi-device host a maintainer would
 // write on the same C ABI (include/kde_hip.h).
 //
-// usage: shard_replay [--frames N] [--width W] [--height H] [--window 11] [--steps K] [--devices G] [--verify]
+// usage: shard_replay [--frames N] [--width W] [--height H] [--window 11] [--steps K] [--warmup W] [--wakeup-ms 150]
+//                     [--devices G] [--frames-file F] [--verify]
+//   Timing follows bench.py: an untimed wake-up load (an idle MI355X sits at its lowest clock level), W warm-up steps,
+//   then K timed steps that all device threads start together; every step is K0 (kde_jbf_presmooth_batch) + K1
+//   (kde_jbf_filter_batch) -- exactly what kde_jbf_process_batch launches -- bracketed by HIP events on the device's
+//   stream, so the per-kernel times are reported per device as bench.py reports them.
+//   --frames-file: raw frames written by `bench.py --dump-frames F` (all colour frames, then all depth frames), so that
+//   the two hosts can be compared on identical input; without it the frames come from the built-in generator.
 //   --verify: the same N frames are also filtered on device 0 alone, as ONE block and as TWO half blocks, and the
 //             per-frame checksums of all three runs must be identical (partition independence, bit for bit).
 // prints one JSON line: per-device times, aggregate Mpixels/s, checksum, "params_broadcast": "rccl" | "single-device".
@@ -57,9 +64,26 @@
 namespace {
 
 struct Options {
-    int frames = 64, width = 640, height = 480, window = 11, steps = 5, devices = 0;
-    float spatial_sigma = 3.0f, color_sigma = 7.65f, depth_sigma = 20.0f;
+    int frames = 64, width = 640, height = 480, window = 11, steps = 20, warmup = 5, devices = 0;
+    float spatial_sigma = 3.0f, color_sigma = 7.65f, depth_sigma = 20.0f, wakeup_ms = 150.0f;
     bool verify = false;
+    std::string frames_file;
+};
+
+// all device threads enter the timed region together (and leave the wake-up together)
+struct SpinBarrier {
+    std::atomic<int> count{0}, generation{0};
+    int parties = 1;
+    void wait()
+    {
+        const int gen = generation.load();
+        if (count.fetch_add(1) + 1 == parties) {
+            count.store(0);
+            generation.fetch_add(1);
+        } else {
+            while (generation.load() == gen) std::this_thread::yield();
+        }
+    }
 };
 
 // deterministic synthetic frame (seed = global frame index): a smooth ramp with rectangles, noise and holes.
@@ -135,13 +159,17 @@ kde_jbf_params unpack_params(const float* blk)
 }
 
 struct ShardResult {
-    double ms_per_step = 0.0;
+    double ms_per_step = 0.0;               // wall time of the K timed steps on this device / K (host clock around the sync)
+    double k0_ms = 0.0, k1_ms = 0.0;        // mean launch time of the two kernels over the timed steps (HIP events)
+    double k1_ms_median = 0.0, k1_ms_min = 0.0;
+    int wakeup_steps = 0;
     std::vector<uint64_t> frame_hash;       // one per frame of the shard
     bool table_matches_rank0 = true;
 };
 
 // filters frames [first, first + count) on `device`; if comm != nullptr the parameter block comes from rank 0's broadcast
-ShardResult run_shard(const Options& o, int device, int rank, int first, int count, ncclComm_t comm, const kde_jbf_params& root_params)
+ShardResult run_shard(const Options& o, int device, int rank, int first, int count, ncclComm_t comm, const kde_jbf_params& root_params,
+                      SpinBarrier* barrier = nullptr)
 {
     ShardResult res;
     KDE_OK_OR_DIE(kde_set_device(device));
@@ -184,22 +212,71 @@ ShardResult run_shard(const Options& o, int device, int rank, int first, int cou
         HIP_OK(hipMalloc(&out_dev, px * count * sizeof(float)));
         std::vector<uint8_t> bgr;
         std::vector<float> depth;
-        for (int f = 0; f < count; f++) {
-            make_frame(first + f, o.width, o.height, bgr, depth);
-            HIP_OK(hipMemcpy(depth_dev + px * f, depth.data(), px * sizeof(float), hipMemcpyHostToDevice));
-            HIP_OK(hipMemcpy(bgr_dev + px * 3 * f, bgr.data(), px * 3, hipMemcpyHostToDevice));
+        if (!o.frames_file.empty()) {
+            // bench.py --dump-frames: o.frames colour frames, then o.frames depth frames
+            FILE* fp = std::fopen(o.frames_file.c_str(), "rb");
+            if (!fp) {
+                std::fprintf(stderr, "cannot open %s\n", o.frames_file.c_str());
+                std::exit(2);
+            }
+            bgr.resize(px * 3 * count);
+            depth.resize(px * count);
+            bool ok = std::fseek(fp, (long)(px * 3 * first), SEEK_SET) == 0 && std::fread(bgr.data(), 1, bgr.size(), fp) == bgr.size();
+            ok = ok && std::fseek(fp, (long)(px * 3 * o.frames + px * 4 * first), SEEK_SET) == 0 &&
+                 std::fread(depth.data(), 4, depth.size(), fp) == depth.size();
+            std::fclose(fp);
+            if (!ok) {
+                std::fprintf(stderr, "%s is shorter than %d frames of %dx%d\n", o.frames_file.c_str(), o.frames, o.width, o.height);
+                std::exit(2);
+            }
+            HIP_OK(hipMemcpy(depth_dev, depth.data(), px * count * sizeof(float), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(bgr_dev, bgr.data(), px * 3 * count, hipMemcpyHostToDevice));
+        } else {
+            for (int f = 0; f < count; f++) {
+                make_frame(first + f, o.width, o.height, bgr, depth);
+                HIP_OK(hipMemcpy(depth_dev + px * f, depth.data(), px * sizeof(float), hipMemcpyHostToDevice));
+                HIP_OK(hipMemcpy(bgr_dev + px * 3 * f, bgr.data(), px * 3, hipMemcpyHostToDevice));
+            }
         }
-        KDE_OK_OR_DIE(kde_jbf_process_batch(jbf, count, depth_dev, bgr_dev, out_dev, stream));   // warm-up
-        hipEvent_t e0, e1;
-        HIP_OK(hipEventCreate(&e0));
-        HIP_OK(hipEventCreate(&e1));
-        HIP_OK(hipEventRecord(e0, stream));
-        for (int k = 0; k < o.steps; k++) KDE_OK_OR_DIE(kde_jbf_process_batch(jbf, count, depth_dev, bgr_dev, out_dev, stream));
-        HIP_OK(hipEventRecord(e1, stream));
-        HIP_OK(hipEventSynchronize(e1));
-        float ms = 0.0f;
-        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
-        res.ms_per_step = ms / o.steps;
+        uint8_t* smooth_dev = nullptr;
+        HIP_OK(hipMalloc(&smooth_dev, px * count * 3));
+        auto step = [&](hipEvent_t* ev) {
+            if (ev) HIP_OK(hipEventRecord(ev[0], stream));
+            KDE_OK_OR_DIE(kde_jbf_presmooth_batch(jbf, count, bgr_dev, smooth_dev, stream));             // K0
+            if (ev) HIP_OK(hipEventRecord(ev[1], stream));
+            KDE_OK_OR_DIE(kde_jbf_filter_batch(jbf, count, depth_dev, smooth_dev, out_dev, stream));     // K1
+            if (ev) HIP_OK(hipEventRecord(ev[2], stream));
+        };
+        // wake-up: untimed load until the device has left its idle clock level (bench.py does the same)
+        const auto tw = std::chrono::steady_clock::now();
+        while (o.wakeup_ms > 0 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count() < o.wakeup_ms) {
+            for (int k = 0; k < 10; k++) step(nullptr);
+            HIP_OK(hipStreamSynchronize(stream));
+            res.wakeup_steps += 10;
+        }
+        for (int k = 0; k < o.warmup; k++) step(nullptr);
+        std::vector<hipEvent_t> ev((size_t)o.steps * 3);
+        for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+        HIP_OK(hipStreamSynchronize(stream));
+        if (barrier) barrier->wait();                         // all devices start their K timed steps together
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < o.steps; k++) step(&ev[(size_t)k * 3]);
+        HIP_OK(hipStreamSynchronize(stream));
+        res.ms_per_step = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / o.steps;
+        std::vector<float> k1(o.steps);
+        for (int k = 0; k < o.steps; k++) {
+            float a = 0.0f, b = 0.0f;
+            HIP_OK(hipEventElapsedTime(&a, ev[(size_t)k * 3], ev[(size_t)k * 3 + 1]));
+            HIP_OK(hipEventElapsedTime(&b, ev[(size_t)k * 3 + 1], ev[(size_t)k * 3 + 2]));
+            res.k0_ms += a / o.steps;
+            res.k1_ms += b / o.steps;
+            k1[k] = b;
+        }
+        std::sort(k1.begin(), k1.end());
+        res.k1_ms_median = k1[k1.size() / 2];
+        res.k1_ms_min = k1.front();
+        for (auto& e : ev) HIP_OK(hipEventDestroy(e));
+        HIP_OK(hipFree(smooth_dev));
         std::vector<float> out(px);
         for (int f = 0; f < count; f++) {
             HIP_OK(hipMemcpy(out.data(), out_dev + px * f, px * sizeof(float), hipMemcpyDeviceToHost));
@@ -209,6 +286,7 @@ ShardResult run_shard(const Options& o, int device, int rank, int first, int cou
         HIP_OK(hipFree(bgr_dev));
         HIP_OK(hipFree(out_dev));
     }
+    else if (barrier) barrier->wait();        // an empty shard still takes part in the common start
     KDE_OK_OR_DIE(kde_jbf_destroy(jbf));
     HIP_OK(hipFree(blk_dev));
     HIP_OK(hipStreamDestroy(stream));
@@ -228,6 +306,9 @@ int main(int argc, char** argv)
         else if (a == "--height") o.height = std::atoi(next());
         else if (a == "--window") o.window = std::atoi(next());
         else if (a == "--steps") o.steps = std::atoi(next());
+        else if (a == "--warmup") o.warmup = std::atoi(next());
+        else if (a == "--wakeup-ms") o.wakeup_ms = (float)std::atof(next());
+        else if (a == "--frames-file") o.frames_file = next();
         else if (a == "--devices") o.devices = std::atoi(next());
         else if (a == "--verify") o.verify = true;
         else {
@@ -259,11 +340,13 @@ int main(int argc, char** argv)
     const int per = (o.frames + G - 1) / G;
     std::vector<ShardResult> results(G);
     std::vector<std::thread> threads;
+    SpinBarrier barrier;
+    barrier.parties = G;
     const auto t0 = std::chrono::steady_clock::now();
     for (int d = 0; d < G; d++)
         threads.emplace_back([&, d]() {
             const int first = std::min(d * per, o.frames), count = std::min(per, o.frames - first);
-            results[d] = run_shard(o, d, d, first, count, comms[d], p);
+            results[d] = run_shard(o, d, d, first, count, comms[d], p, &barrier);
         });
     for (auto& t : threads) t.join();
     const double wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -272,11 +355,18 @@ int main(int argc, char** argv)
     double slowest = 0.0;
     bool tables_ok = true;
     std::vector<uint64_t> hashes;
+    std::string per_dev = "[";
     for (int d = 0; d < G; d++) {
         slowest = std::max(slowest, results[d].ms_per_step);
+        char buf[256];
+        std::snprintf(buf, sizeof(buf), "%s{\"device\": %d, \"ms_per_step\": %.4f, \"k0_ms\": %.4f, \"k1_ms\": %.4f, \"k1_ms_median\": %.4f, "
+                      "\"k1_ms_min\": %.4f}", d ? ", " : "", d, results[d].ms_per_step, results[d].k0_ms, results[d].k1_ms,
+                      results[d].k1_ms_median, results[d].k1_ms_min);
+        per_dev += buf;
         tables_ok = tables_ok && results[d].table_matches_rank0;
         hashes.insert(hashes.end(), results[d].frame_hash.begin(), results[d].frame_hash.end());
     }
+    per_dev += "]";
     uint64_t all = 1469598103934665603ull;
     for (uint64_t h : hashes) all = (all ^ h) * 1099511628211ull;
 
@@ -292,9 +382,12 @@ int main(int argc, char** argv)
     }
     const double mpix = (double)o.frames * o.width * o.height / (slowest * 1e-3) / 1e6;
     std::printf("{\"devices\": %d, \"frames\": %d, \"frames_per_device\": %d, \"width\": %d, \"height\": %d, \"window\": %d, "
-                "\"ms_per_step_slowest_device\": %.4f, \"mpixels_per_s\": %.1f, \"params_broadcast\": \"%s\", "
+                "\"steps\": %d, \"warmup\": %d, \"wakeup_steps_before_warmup\": %d, \"input\": \"%s\", "
+                "\"ms_per_step_slowest_device\": %.4f, \"mpixels_per_s\": %.1f, \"per_device\": %s, \"params_broadcast\": \"%s\", "
                 "\"tables_match_rank0\": %s, \"checksum\": \"%016llx\", \"verified\": %s, \"wall_s\": %.2f}\n",
-                G, o.frames, per, o.width, o.height, o.window, slowest, mpix, "rccl ncclBroadcast", tables_ok ? "true" : "false",
+                G, o.frames, per, o.width, o.height, o.window, o.steps, o.warmup, results[0].wakeup_steps,
+                o.frames_file.empty() ? "built-in generator" : "frames file (bench.py --dump-frames)", slowest, mpix, per_dev.c_str(),
+                "rccl ncclBroadcast", tables_ok ? "true" : "false",
                 (unsigned long long)all, o.verify ? (verified ? "true" : "false") : "null", wall_s);
     return (tables_ok && verified) ? 0 : 1;
 }

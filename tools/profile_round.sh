@@ -13,11 +13,13 @@
 #   chain       tools/bench_chain.py at 1080p and 640x480, tools/bench_spdsr.py, tools/bench_mrf.py
 #   sweep       K1 variant / tile sweeps (BASELINE config 3)
 #   micro       tools/valu_microbench (VALU issue costs)
+#   shard       the C++ sharding host (examples/shard_replay, RCCL broadcast) against bench.py on IDENTICAL frames
+#               (bench.py --dump-frames -> shard_replay --frames-file): the two N = 1 figures must agree
 # PMC passes hold one counter group each and no tracing domain (MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -eo pipefail
 TAG=${1:-final}
 shift || true
-STEPS=${*:-pmc_bench pmc_chain pmc_feeders stats bench chain sweep micro}
+STEPS=${*:-pmc_bench pmc_chain pmc_feeders stats bench chain sweep micro shard}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -105,6 +107,26 @@ sweep)
     python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 7 --spatial-sigma 70 --color-sigma 50 --depth-sigma 20
     python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window 5 --spatial-sigma 70 --color-sigma 50 --depth-sigma 20 --with-generic
   } > "$OUT/sweep_k1_variants.log" 2> "$OUT/sweep.err"
+  ;;
+shard)
+  python3 bench.py --cpu-seconds 0 --no-extra --no-verify --dump-frames /tmp/kde_frames.bin > "$OUT/shard_bench_py.json" 2> "$OUT/shard.err"
+  examples/shard_replay --frames 64 --frames-file /tmp/kde_frames.bin > "$OUT/shard_replay_same_frames.json" 2>> "$OUT/shard.err"
+  examples/shard_replay --frames 64 > "$OUT/shard_replay_builtin_frames.json" 2>> "$OUT/shard.err"
+  rm -f /tmp/kde_frames.bin
+  python3 - "$OUT" <<'PY'
+import json, sys
+out = sys.argv[1]
+last = lambda path: json.loads([ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1])   # RCCL prints a banner on stdout
+b = last(f"{out}/shard_bench_py.json")
+s = last(f"{out}/shard_replay_same_frames.json")
+g = last(f"{out}/shard_replay_builtin_frames.json")
+cmp_ = {"bench_py": {"mpixels_per_s": b["value"], "ms_per_step": b["ms_per_step"], "k0_ms": b["roofline"]["k0_avg_launch_ms"], "k1_ms": b["roofline"]["avg_launch_ms"]},
+        "shard_replay_same_frames": {"mpixels_per_s": s["mpixels_per_s"], "ms_per_step": s["ms_per_step_slowest_device"], **{k: s["per_device"][0][k] for k in ("k0_ms", "k1_ms")}},
+        "shard_replay_builtin_frames": {"mpixels_per_s": g["mpixels_per_s"], "ms_per_step": g["ms_per_step_slowest_device"], **{k: g["per_device"][0][k] for k in ("k0_ms", "k1_ms")}},
+        "ratio_same_frames": s["mpixels_per_s"] / b["value"], "ratio_builtin_frames": g["mpixels_per_s"] / b["value"]}
+json.dump(cmp_, open(f"{out}/shard_vs_bench.json", "w"), indent=1)
+print(json.dumps(cmp_))
+PY
   ;;
 micro)
   tools/valu_microbench > "$OUT/valu_microbench.txt" 2>&1
