@@ -154,13 +154,24 @@ struct PreDev {
 };
 
 constexpr int kPreBX = 16, kPreBY = 16;
+
+// D = old with byte `byte` replaced by saturate_u8(round-half-even(v))
+__device__ __forceinline__ uint32_t cvt_pk_u8(float v, uint32_t byte, uint32_t old)
+{
+    uint32_t r;
+    asm("v_cvt_pk_u8_f32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(byte), "v"(old));
+    return r;
+}
 typedef float pre_f2 __attribute__((ext_vector_type(2)));
 constexpr int kPreTH = kPreBY;
 
 // PX = horizontally adjacent pixels per thread: 4 amortises the byte -> float conversions best, 2 halves the
 // registers (7 instead of 4 waves per SIMD) -- the kernel is latency-bound on its LDS table gathers
+#ifndef KDE_K0_RP_WAVES
+#define KDE_K0_RP_WAVES 7      // waves per SIMD the allocator must leave room for (radii 1, 2): 72 VGPRs, measured 0.103 vs 0.127 (no cap, 78 VGPRs) / 0.114 (8) ms on 64 x VGA
+#endif
 template <int R, int PX>
-__global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
+__global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) void presmooth_kernel(PreDev a)
 {
     constexpr int kPrePX = PX, kPreTW = kPreBX * PX;
     constexpr int NT = kPreBX * kPreBY;
@@ -285,11 +296,6 @@ __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
                 }
             }
         }
-        auto sat = [](float x) -> uint32_t {      // saturate_cast<uchar>: round half to even, clamp
-            if (!(x > 0.0f)) return 0u;
-            if (x >= 255.0f) return 255u;
-            return (uint32_t)rintf(x);
-        };
         // The reference divides (IEEE) and rounds half-to-even to u8.  rcp + one Newton step is within 1 ulp
         // (< 1.6e-5 below 256) of the quotient, which rounds to the same integer unless the quotient sits within
         // that distance of k + 0.5; those (rare) lanes take the IEEE division, so the byte is the reference's.
@@ -305,14 +311,15 @@ __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
                 const float num = q[c];
                 const float q0 = num * r;
                 q[c] = __builtin_fmaf(__builtin_fmaf(-den, q0, num), r, q0);
-                ambiguous |= !(__builtin_fabsf(__builtin_fabsf(q[c] - rintf(q[c])) - 0.5f) > 1.0e-4f);   // NaN -> exact path
+                ambiguous |= !(__builtin_fabsf(__builtin_amdgcn_fractf(q[c]) - 0.5f) > 1.0e-4f);   // NaN -> exact path
             }
             if (ambiguous) {
                 q[0] = sbg[k].x / den;
                 q[1] = sbg[k].y / den;
                 q[2] = srw[k].x / den;
             }
-            px[k] = sat(q[0]) | (sat(q[1]) << 8) | (sat(q[2]) << 16);
+            // saturate_cast<uchar>: v_cvt_pk_u8_f32 rounds to nearest even, clamps to [0, 255] and packs the byte
+            px[k] = cvt_pk_u8(q[2], 2u, cvt_pk_u8(q[1], 1u, cvt_pk_u8(q[0], 0u, 0u)));
         }
         uint8_t* o = a.dst + (frame + (size_t)y * a.width + xb) * 3;
         if (PX == 4 && (a.width & 3) == 0 && xb + 3 < a.width && (reinterpret_cast<uintptr_t>(a.dst) & 3u) == 0) {
@@ -333,6 +340,189 @@ __global__ __launch_bounds__(kPreBX* kPreBY) void presmooth_kernel(PreDev a)
                     o[3 * k + 1] = (uint8_t)((px[k] >> 8) & 0xff);
                     o[3 * k + 2] = (uint8_t)((px[k] >> 16) & 0xff);
                 }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// K0, 2 x 2 pixels per thread (r03; the default for radii 1..4).  The kernel above is bound by the VALU instructions
+// it issues (184 per pixel at radius 2: 45 byte -> float conversions, 65 for the 13 taps, ~50 for the quotient /
+// rounding / packing), not by memory.  A thread that owns a 2 x 2 block loads each of its 2R + 2 window rows ONCE for
+// both output rows: 27 instead of 45 conversions per pixel; (r, weight) accumulate as one packed pair like (b, g):
+// 4 instead of 5 instructions per tap; the epilogue tests "is the quotient within 1e-4 of a rounding boundary" on its
+// fractional part and converts with v_cvt_pk_u8_f32 (round-to-nearest-even, saturating, packing: the reference's
+// saturate_cast<uchar>).  Same tap order per pixel (dy outer, dx inner), same fma / division semantics: same bytes.
+// --------------------------------------------------------------------------------------------
+constexpr int kPre22TW = kPreBX * 2, kPre22TH = kPreBY * 2;       // 32 x 32 pixels per workgroup
+#ifndef KDE_K0_WAVES
+#define KDE_K0_WAVES 5
+#endif
+constexpr int kPre22Waves = KDE_K0_WAVES;       // waves per SIMD the register allocator must leave room for (latency-bound on LDS gathers)
+
+template <int R, int WAVES>
+__global__ __launch_bounds__(kPreBX* kPreBY, WAVES) void presmooth22_kernel(PreDev a)
+{
+    constexpr int NT = kPreBX * kPreBY;
+    constexpr int LW = kPre22TW + 2 * R, LH = kPre22TH + 2 * R;
+    constexpr int LUT_N = (R * R + 1) * 766;
+    constexpr int SEG = 2 + 2 * R;                       // window columns of a pixel pair (even)
+    constexpr int ROWS = 2 + 2 * R;                      // window rows of the two output rows
+    constexpr int LP = (LW + 1) / 2 * 2;                 // LDS row pitch (even: a pair's segment starts 8-byte aligned)
+    __shared__ float lut[LUT_N];
+    __shared__ __attribute__((aligned(16))) uint32_t sc[LH * LP + 4];
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < LUT_N; i += NT) lut[i] = a.lut[i];
+
+    const int tiles_per_frame = a.tiles_x * a.tiles_y;
+    const int total = tiles_per_frame * a.n;
+    const int tx = tid % kPreBX, ty = tid / kPreBX;
+
+    constexpr int NSLOT = (LW * LH + NT - 1) / NT;
+    // staging slot k of this thread: element tid + k NT of the (LW x LH) tile; its coordinates are recomputed where they
+    // are used (a multiply-shift each) instead of living in 2 NSLOT registers across the tap loop
+    auto slot_y = [&](int k) { return (int)(((unsigned)(tid + k * NT) * ((1u << 20) / LW + 1u)) >> 20); };     // (tid + k NT) / LW, exact for < 4096
+    auto slot_x = [&](int k) { return tid + k * NT - slot_y(k) * LW; };
+    static_assert(LW * LH < 4096, "slot division");
+    const size_t last_pix = (size_t)a.n * a.width * a.height - 1;     // its 4-byte read would leave the buffer
+    auto fetch = [&](int t, uint32_t* pre) {
+        const int frame_i = t / tiles_per_frame;
+        const int tile = t - frame_i * tiles_per_frame;
+        const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+        const size_t frame = (size_t)frame_i * a.width * a.height;
+        const bool inner = txi * kPre22TW - R >= 0 && txi * kPre22TW + kPre22TW + R <= a.width && tyi * kPre22TH - R >= 0 &&
+                           tyi * kPre22TH + kPre22TH + R <= a.height;
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) {
+            if (tid + k * NT < LW * LH) {
+                const int ux = txi * kPre22TW + slot_x(k) - R, uy = tyi * kPre22TH + slot_y(k) - R;
+                const int gx = inner ? ux : reflect101(ux, a.width);
+                const int gy = inner ? uy : reflect101(uy, a.height);
+                const size_t pix = frame + (size_t)gy * a.width + gx;
+                if (pix < last_pix) {
+                    uint32_t v;
+                    __builtin_memcpy(&v, a.src + pix * 3, 4);          // one (unaligned) global_load_dword
+                    pre[k] = v & 0x00ffffffu;
+                } else {
+                    pre[k] = load_bgrx(a.src, pix);
+                }
+            }
+        }
+    };
+
+    uint32_t pre[NSLOT];
+    if ((int)blockIdx.x < total) fetch(blockIdx.x, pre);
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int frame_i = t / tiles_per_frame;
+        const int tile = t - frame_i * tiles_per_frame;
+        const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+        const int x0 = txi * kPre22TW, y0 = tyi * kPre22TH;
+        const size_t frame = (size_t)frame_i * a.width * a.height;
+
+        __syncthreads();   // previous tile fully consumed (also orders the LUT staging before first use)
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++)
+            if (tid + k * NT < LW * LH) sc[slot_y(k) * LP + slot_x(k)] = pre[k];
+        __syncthreads();
+        if (t + (int)gridDim.x < total) fetch(t + gridDim.x, pre);
+
+        const int xb = x0 + 2 * tx, yb = y0 + 2 * ty;
+        if (xb >= a.width || yb >= a.height) continue;
+
+        // [output row][pixel of the pair]: (b, g) and (r, weight sum) as packed pairs
+        uint32_t cc[2][2];
+        pre_f2 sbg[2][2], srw[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                cc[j][k] = sc[(2 * ty + R + j) * LP + 2 * tx + R + k];
+                sbg[j][k] = srw[j][k] = pre_f2{0.0f, 0.0f};
+            }
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {               // window row r of the block = staged row 2 ty + r
+            // one row in flight at a time: without the fence the scheduler hoists the LDS reads and conversions of all
+            // 2R + 2 rows to the top (146 VGPRs at radius 2: 3 waves per SIMD, and the kernel lives on resident waves)
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t v[SEG];
+            pre_f2 fbg[SEG], frw[SEG];
+#pragma unroll
+            for (int q2 = 0; q2 < SEG / 2; q2++) {
+                const uint2 w = *reinterpret_cast<const uint2*>(&sc[(2 * ty + r) * LP + 2 * tx + 2 * q2]);
+                v[2 * q2] = w.x;
+                v[2 * q2 + 1] = w.y;
+            }
+#pragma unroll
+            for (int q = 0; q < SEG; q++) {
+                fbg[q] = pre_f2{(float)(v[q] & 0xffu), (float)((v[q] >> 8) & 0xffu)};
+                frw[q] = pre_f2{(float)((v[q] >> 16) & 0xffu), 1.0f};
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {               // output row j sees this row as dy = r - R - j
+                const int dy = r - R - j;
+                if (dy < -R || dy > R) continue;
+#pragma unroll
+                for (int dx = -R; dx <= R; dx++) {
+                    const int space2 = dx * dx + dy * dy;
+                    if (space2 > R * R) continue;        // same tap order as the reference kernel: cy outer, cx inner
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const int q = k + R + dx;
+                        const uint32_t n1 = __builtin_amdgcn_sad_u8(v[q], cc[j][k], 0u);   // |db| + |dg| + |dr|
+                        const float w = lut[space2 * 766 + n1];
+                        const pre_f2 ww = pre_f2{w, w};
+                        sbg[j][k] = __builtin_elementwise_fma(ww, fbg[q], sbg[j][k]);
+                        srw[j][k] = __builtin_elementwise_fma(ww, frw[q], srw[j][k]);       // (w r + s, w 1 + sum): fma(w, 1, s) == w + s
+                    }
+                }
+            }
+        }
+        // The reference divides (IEEE) and rounds half-to-even to u8.  rcp + one Newton step is within 1 ulp
+        // (< 1.6e-5 below 256) of the quotient, which rounds to the same integer unless the quotient sits within
+        // that distance of k + 0.5; those (rare) lanes take the IEEE division, so the byte is the reference's.
+        uint32_t px[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const float den = srw[j][k].y;
+                const float rc = __builtin_amdgcn_rcpf(den);
+                float q[3] = {sbg[j][k].x, sbg[j][k].y, srw[j][k].x};
+                bool ambiguous = false;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float num = q[c];
+                    const float q0 = num * rc;
+                    q[c] = __builtin_fmaf(__builtin_fmaf(-den, q0, num), rc, q0);
+                    ambiguous |= !(__builtin_fabsf(__builtin_amdgcn_fractf(q[c]) - 0.5f) > 1.0e-4f);   // NaN -> exact path
+                }
+                if (ambiguous) {
+                    q[0] = sbg[j][k].x / den;
+                    q[1] = sbg[j][k].y / den;
+                    q[2] = srw[j][k].x / den;
+                }
+                // saturate_cast<uchar>: v_cvt_pk_u8_f32 rounds to nearest even, clamps to [0, 255] and packs
+                px[j][k] = cvt_pk_u8(q[2], 2u, cvt_pk_u8(q[1], 1u, cvt_pk_u8(q[0], 0u, 0u)));
+            }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int y = yb + j;
+            if (y >= a.height) continue;
+            uint8_t* o = a.dst + (frame + (size_t)y * a.width + xb) * 3;
+            if (xb + 1 < a.width && (reinterpret_cast<uintptr_t>(o) & 1u) == 0) {
+                uint16_t* oh = reinterpret_cast<uint16_t*>(o);                  // 2 pixels = 6 bytes = 3 halfwords
+                oh[0] = (uint16_t)(px[j][0] & 0xffffu);
+                oh[1] = (uint16_t)((px[j][0] >> 16) | ((px[j][1] & 0xffu) << 8));
+                oh[2] = (uint16_t)(px[j][1] >> 8);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+                    if (xb + k < a.width) {
+                        o[3 * k] = (uint8_t)(px[j][k] & 0xff);
+                        o[3 * k + 1] = (uint8_t)((px[j][k] >> 8) & 0xff);
+                        o[3 * k + 2] = (uint8_t)((px[j][k] >> 16) & 0xff);
+                    }
+            }
         }
     }
 }
@@ -480,6 +670,14 @@ int launch_jbf(const JbfLaunch& a, hipStream_t s)
 // belongs to the device it was created on -- so nothing is cached across devices or threads here.
 constexpr int kPrePxPerThread = 2;                          // pixels per thread (A/B: 4)
 
+// A/B switch (tools/bench_k0.py): KDE_K0_2X2=1 selects the 2 x 2-pixels-per-thread form for radii 1 and 2.  It issues 25 %
+// fewer instructions but needs 146 VGPRs (3 waves per SIMD instead of 6) and measured 0.146 vs 0.115 ms on 64 x VGA.
+static bool k0_use_2x2()
+{
+    static const bool v = getenv("KDE_K0_2X2") != nullptr;
+    return v;
+}
+
 long long presmooth_resident_blocks(int radius)
 {
     auto resident = [](auto kernel) -> long long {
@@ -494,9 +692,9 @@ long long presmooth_resident_blocks(int radius)
         return (long long)cus * per_cu;
     };
     switch (radius) {
-        case 1: return resident(presmooth_kernel<1, kPrePxPerThread>);
-        case 2: return resident(presmooth_kernel<2, kPrePxPerThread>);
-        case 3: return resident(presmooth_kernel<3, kPrePxPerThread>);
+        case 1: return k0_use_2x2() ? resident(presmooth22_kernel<1, kPre22Waves>) : resident(presmooth_kernel<1, kPrePxPerThread>);
+        case 2: return k0_use_2x2() ? resident(presmooth22_kernel<2, kPre22Waves>) : resident(presmooth_kernel<2, kPrePxPerThread>);
+        case 3: return resident(presmooth_kernel<3, kPrePxPerThread>);     // radii 3, 4: the 2 x 2 form needs > 300 VGPRs
         case 4: return resident(presmooth_kernel<4, kPrePxPerThread>);
         default: return 0;                                  // generic kernel: a plain grid
     }
@@ -512,8 +710,9 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
     d.height = a.height;
     d.n = a.n;
     constexpr int kPX = kPrePxPerThread;
-    d.tiles_x = ceil_div(a.width, kPreBX * kPX);
-    d.tiles_y = ceil_div(a.height, kPreTH);
+    const bool old_form = a.radius > 2 || !k0_use_2x2();
+    d.tiles_x = ceil_div(a.width, old_form ? kPreBX * kPX : kPre22TW);
+    d.tiles_y = ceil_div(a.height, old_form ? kPreTH : kPre22TH);
     if (a.radius < 1) return fail(KDE_ERR_INVALID, "presmooth: radius %d", a.radius);
     if (a.radius > 4) {
         if (a.n > 65535) return fail(KDE_ERR_INVALID, "presmooth: batch too large for one launch");
@@ -526,11 +725,16 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
     if (total > 0x7fffffffLL) return fail(KDE_ERR_INVALID, "presmooth: batch too large for one launch");
     const long long cap = a.grid_cap > 0 ? a.grid_cap : 256;
     const unsigned grid = (unsigned)(total < cap ? total : cap);
-    switch (a.radius) {
-        case 1: hipLaunchKernelGGL((presmooth_kernel<1, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
-        case 2: hipLaunchKernelGGL((presmooth_kernel<2, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
-        case 3: hipLaunchKernelGGL((presmooth_kernel<3, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
-        default: hipLaunchKernelGGL((presmooth_kernel<4, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
+    if (old_form) {
+        switch (a.radius) {
+            case 1: hipLaunchKernelGGL((presmooth_kernel<1, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
+            case 2: hipLaunchKernelGGL((presmooth_kernel<2, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
+            case 3: hipLaunchKernelGGL((presmooth_kernel<3, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
+            default: hipLaunchKernelGGL((presmooth_kernel<4, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
+        }
+    } else {
+        if (a.radius == 1) hipLaunchKernelGGL((presmooth22_kernel<1, kPre22Waves>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d);
+        else hipLaunchKernelGGL((presmooth22_kernel<2, kPre22Waves>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d);
     }
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
