@@ -11,6 +11,8 @@
 // to ~1e-15 relative before the cast to float.
 #include "kde_internal.h"
 
+#include <type_traits>
+
 namespace kde {
 namespace {
 
@@ -311,6 +313,127 @@ __global__ __launch_bounds__(kSwBX* kSwBY) void mrf_sweep_kernel(int width, int 
     if (has1) zout[p + 1] = rw1 ? -oz.y : oz.y;
 }
 
+// Two sweeps per launch (temporal blocking) -- MEASURED AND NOT USED BY DEFAULT (KDE_SPDSR_TWO_SWEEPS=1 selects it).
+// A single sweep moves 12 B per pixel and is half latency (VALU busy 0.43 at 1080p, 20 launches of 16 us each); here a
+// workgroup that owns a 64 x 32 tile stages the z plane with a halo of 4, evaluates sweep k on the tile + a halo of 2
+// (68 x 36 = 1.2 x the tile) into LDS, and sweep k + 1 on the tile from there.  Per pixel the arithmetic is exactly
+// mrf_sweep_kernel's (tests/test_gpu_dasp_ers.py: same bits), but it is 3 % slower at 1080p and 15 % at 640x480: fewer,
+// longer workgroups expose the same latency chain with less of the GPU occupied.  (r02 had measured the same loss on a
+// 64 x 8 tile, where the recomputed halo is 1.6 x the tile.)
+constexpr int kSw2TW = 64, kSw2TH = 32;
+__global__ __launch_bounds__(256) void mrf_sweep2_kernel(int width, int height, const float* __restrict__ zin,
+                                                         const float* __restrict__ pfz, float* __restrict__ zout)
+{
+    constexpr int WIN = 5, HALF = 2;
+    constexpr int AW = kSw2TW + 8, AH = kSw2TH + 8;        // staged input: halo 4
+    constexpr int BW = kSw2TW + 4, BH = kSw2TH + 4;        // first sweep's result: halo 2
+    __shared__ __attribute__((aligned(8))) float sa[AH * AW];       // |z| if > 50 else 0 (what a tap sees)
+    __shared__ __attribute__((aligned(8))) float sb[BH * BW];       // signed state after the first sweep
+    __shared__ __attribute__((aligned(8))) float sp[BH * BW];       // plane-fitted z of the same region
+    {
+        const size_t fpx = (size_t)blockIdx.z * width * height;    // blockIdx.z = frame of a batch
+        zin += fpx; pfz += fpx; zout += fpx;
+    }
+    const int x0 = blockIdx.x * kSw2TW, y0 = blockIdx.y * kSw2TH;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < AW * AH; i += 256) {
+        const int ly = i / AW, lx = i - ly * AW;
+        const int gx = x0 + lx - 4, gy = y0 + ly - 4;
+        float z = 0.0f;
+        if (gx >= 0 && gx < width && gy >= 0 && gy < height) z = fabsf(zin[(size_t)gy * width + gx]);
+        sa[i] = z > 50.0f ? z : 0.0f;
+    }
+    __syncthreads();
+    const s_f2 one = {1.0f, 1.0f}, half = {0.5f, 0.5f};
+    // one pixel pair of one sweep: taps from `plane` (pitch P, the pair's window starts at plane[row0 * P + col0], col0
+    // even), own signed state zs, plane-fitted z pf -> new signed state.  Identical to the body of mrf_sweep_kernel.
+    auto sweep_pair = [&](const float* plane, int P, int row0, int col0, s_f2 zs, s_f2 pf, auto absval) -> s_f2 {
+        s_f2 oz = {fabsf(zs.x), fabsf(zs.y)};
+        bool rw0 = zs.x < 0.0f, rw1 = zs.y < 0.0f;
+        const bool c0 = pf.x > 50.0f && fabsf(oz.x - pf.x) < oz.x * 0.01f;
+        const bool c1 = pf.y > 50.0f && fabsf(oz.y - pf.y) < oz.y * 0.01f;
+        if (c0 || c1) {
+            s_f2 num = pf, den = {1.0f, 1.0f};
+#pragma unroll
+            for (int i = 0; i < WIN; i++) {
+                s_f2 q[3], hv[3];
+#pragma unroll
+                for (int m = 0; m < 3; m++) {
+                    q[m] = *reinterpret_cast<const s_f2*>(&plane[(row0 + i) * P + col0 + 2 * m]);
+                    if constexpr (decltype(absval)::value) {         // the intermediate plane holds signed state: taps see |z| > 50
+                        q[m] = s_f2{fabsf(q[m].x), fabsf(q[m].y)};
+                        q[m] = s_f2{q[m].x > 50.0f ? q[m].x : 0.0f, q[m].y > 50.0f ? q[m].y : 0.0f};
+                    }
+                    hv[m] = s_add_clamp(q[m], q[m]) * half;
+                }
+#pragma unroll
+                for (int u = 0; u < WIN; u++) {
+                    s_f2 oq, h;
+                    if (u <= HALF) {
+                        oq = q[u];
+                        h = hv[u];
+                    } else if (u < WIN - 1) {
+                        oq = __builtin_shufflevector(q[u - HALF], q[u - HALF], 1, 0);
+                        h = __builtin_shufflevector(hv[u - HALF], hv[u - HALF], 1, 0);
+                    } else {
+                        oq = s_f2{q[0].y, q[HALF].x};
+                        h = s_f2{hv[0].y, hv[HALF].x};
+                    }
+                    const s_f2 diff = oz - oq;
+                    const s_f2 t1 = one + diff * diff;
+                    const s_f2 filter = s_f2{__builtin_amdgcn_rcpf(t1.x), __builtin_amdgcn_rcpf(t1.y)} * h;
+                    num = __builtin_elementwise_fma(oq, filter, num);
+                    den = den + filter;
+                }
+            }
+            if (c0 && den.x != 0.0f) {
+                oz.x = num.x / den.x;
+                rw0 = true;
+            }
+            if (c1 && den.y != 0.0f) {
+                oz.y = num.y / den.y;
+                rw1 = true;
+            }
+        }
+        return s_f2{rw0 ? -oz.x : oz.x, rw1 ? -oz.y : oz.y};
+    };
+    // ---- first sweep on the tile + halo 2 (BW x BH, pairs) ----
+    for (int i = tid; i < (BW / 2) * BH; i += 256) {
+        const int by = i / (BW / 2), bx = 2 * (i - by * (BW / 2));
+        const int gx = x0 + bx - 2, gy = y0 + by - 2;
+        s_f2 zs = {0.0f, 0.0f}, pf = {0.0f, 0.0f};
+        const bool in_y = gy >= 0 && gy < height;
+        const bool in0 = in_y && gx >= 0 && gx < width, in1 = in_y && gx + 1 >= 0 && gx + 1 < width;
+        if (in0) {
+            zs.x = zin[(size_t)gy * width + gx];
+            pf.x = pfz[(size_t)gy * width + gx];
+        }
+        if (in1) {
+            zs.y = zin[(size_t)gy * width + gx + 1];
+            pf.y = pfz[(size_t)gy * width + gx + 1];
+        }
+        s_f2 r = sweep_pair(sa, AW, by, bx, zs, pf, std::false_type{});
+        // a pixel outside the image never is a tap (it stages as 0) and never is written
+        if (!in0) r.x = 0.0f;
+        if (!in1) r.y = 0.0f;
+        *reinterpret_cast<s_f2*>(&sb[by * BW + bx]) = r;
+        *reinterpret_cast<s_f2*>(&sp[by * BW + bx]) = pf;
+    }
+    __syncthreads();
+    // ---- second sweep on the tile, taps and own state from the first sweep's result ----
+    for (int i = tid; i < (kSw2TW / 2) * kSw2TH; i += 256) {
+        const int ty = i / (kSw2TW / 2), tx = 2 * (i - ty * (kSw2TW / 2));
+        const int x = x0 + tx, y = y0 + ty;
+        if (x >= width || y >= height) continue;
+        const s_f2 zs = *reinterpret_cast<const s_f2*>(&sb[(ty + 2) * BW + tx + 2]);
+        const s_f2 pf = *reinterpret_cast<const s_f2*>(&sp[(ty + 2) * BW + tx + 2]);
+        const s_f2 r = sweep_pair(sb, BW, ty, tx, zs, pf, std::true_type{});
+        const size_t p = (size_t)y * width + x;
+        zout[p] = r.x;
+        if (x + 1 < width) zout[p + 1] = r.y;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void mrf_expand_kernel(int npix, const float* __restrict__ zfinal,
                                                              const kde_float3* __restrict__ pts,
                                                              const float2* __restrict__ nxy, kde_float3* __restrict__ out)
@@ -377,7 +500,18 @@ int launch_spdsr_plane_projection(int width, int height, int n, int nclusters, c
                        zping, pfz);
     float *in = zping, *out = zpong;
     dim3 grid(ceil_div(width, kSwBX * 2), ceil_div(height, kSwBY), n);
-    for (int i = 0; i < sweeps; i++) {
+    // A/B switch for tools/bench_spdsr.py.  Measured on MI355X (r03): two sweeps per launch are bit-identical and SLOWER --
+    // 0.978 vs 0.946 ms per 1080p frame, 0.383 vs 0.333 at 640x480 (150 workgroups there) -- so one sweep per launch stays.
+    static const bool two_sweeps = getenv("KDE_SPDSR_TWO_SWEEPS") != nullptr;
+    dim3 grid2(ceil_div(width, kSw2TW), ceil_div(height, kSw2TH), n);
+    int i = 0;
+    for (; two_sweeps && i + 1 < sweeps; i += 2) {      // two sweeps per launch (mrf_sweep2_kernel)
+        hipLaunchKernelGGL(mrf_sweep2_kernel, grid2, dim3(256), 0, s, width, height, in, pfz, out);
+        float* t = in;
+        in = out;
+        out = t;
+    }
+    for (; i < sweeps; i++) {
         hipLaunchKernelGGL(mrf_sweep_kernel, grid, dim3(kSwBX * kSwBY), 0, s, width, height, in, pfz, out);
         float* t = in;
         in = out;

@@ -593,3 +593,33 @@ def test_fastdiv24_device_function_equals_integer_division(torch_cuda):
         got, (m, sh, ok) = probe(d, maxdiv, big)
         assert ok == 0, (d, maxdiv)
         assert np.array_equal(got, big // np.uint32(d)), (d, maxdiv)
+
+
+def test_spdsr_two_sweeps_per_launch_equal_single_sweeps_bitwise(torch_cuda, tmp_path):
+    """The measured-and-rejected two-sweeps-per-launch form of Projection_GPU's 20 mrf_optimization sweeps
+    (mrf_sweep2_kernel, KDE_SPDSR_TWO_SWEEPS=1, read once per process): per pixel the arithmetic is the single-sweep
+    kernel's, so the optimised cloud must not change by a bit.  Ragged size: partial tiles and an odd width."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from kinectdepthmapenhancement_amd import filters as F, synth\n"
+        "from oracle import oracle as O\n"
+        "outs = []\n"
+        "for (w, h, g) in ((203, 131, (5, 7)), (320, 240, (6, 8))):\n"
+        "    bgr, depth = synth.make_frame(33, w, h); K = synth.intrinsics(w, h)\n"
+        "    pts = O.p2r_depth(depth, K).view(np.float32).reshape(h, w, 3)\n"
+        "    sr = F.SPDepthSuperResolution(w, h); sr.SetParametor(g[0], g[1], K)\n"
+        "    sr.Process(torch.from_numpy(depth).cuda(), torch.from_numpy(np.ascontiguousarray(pts)).cuda(), torch.from_numpy(bgr).cuda())\n"
+        "    outs.append(sr.getOptimizedPoints_Device().cpu().numpy().ravel())\n"
+        "np.save(sys.argv[1], np.concatenate(outs))\n") % ROOT
+    res = []
+    for tag, extra in (("two", {"KDE_SPDSR_TWO_SWEEPS": "1"}), ("one", {})):
+        path = str(tmp_path / f"opt_{tag}.npy")
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(path))
+    assert res[0].shape == res[1].shape and np.isfinite(res[0]).mean() > 0.9
+    assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
