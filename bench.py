@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--share-device", action="store_true",
                     help="every rank uses cuda:0 (rehearsal of the N > 1 path on a one-GPU box; needs --backend gloo)")
     ap.add_argument("--first-frame", type=int, default=0, help="global index of the first frame (N = 1 runs of one shard of a larger batch)")
+    ap.add_argument("--no-idle-leg", action="store_true", help="skip the from-idle measurement that precedes the headline (profiling runs)")
     ap.add_argument("--dump-frames", default="",
                     help="write this rank's input frames (all colour frames, then all depth frames, raw) for examples/shard_replay --frames-file")
     ap.add_argument("--dry-run", action="store_true",
@@ -113,11 +114,13 @@ def launch_ranks(args):
     return max(abs(q.returncode) for q in procs)
 
 
-def pmc_lookup(path, window):
-    """K1 entry of the committed PMC table (tools/pmc_report.py) for this window: the launch with the largest grid.
+def pmc_lookup(path, window, variant_name=None):
+    """K1 entry of the committed PMC table (tools/pmc_report.py) for the kernel that actually ran: the template instance of
+    `variant_name` ("w11-pk2-16x16-false-v4[-noelide]" / "w11-sc2-16x16-false"), the launch with the largest grid.
     Only used when the table was taken on exactly these kernel sources."""
     try:
         import importlib.util
+        import re
         spec = importlib.util.spec_from_file_location("pmc_report", os.path.join(ROOT, "tools", "pmc_report.py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
@@ -125,9 +128,18 @@ def pmc_lookup(path, window):
         pj = json.load(open(path))
         if pj.get("kernel_source_sha16") != source_hash():
             return None, "profile is stale (kernel sources changed since tools/profile_round.sh ran)"
-        c = [k for k in pj["kernels"] if (f"jbf_pk_kernel<{window}," in k["kernel"] or f"jbf_fast_kernel<{window}," in k["kernel"])]
+        pat = rf"jbf_(pk|fast)_kernel<{window},"
+        m = re.match(r"w(\d+)-(pk|sc)(\d+)-(\d+)x(\d+)-(true|false)(-v[14])?(-noelide)?$", variant_name or "")
+        if m:
+            w, kind, npx, bx, by, cache, vl, noel = m.groups()
+            if kind == "pk":     # jbf_pk_kernel<WIN, NP, BX, BY, CACHE, CSKIP, VL, ELIDE_ON>
+                pat = (rf"jbf_pk_kernel<{w}, {npx}, {bx}, {by}, {cache}, (true|false), {'true' if vl == '-v4' else 'false'}, "
+                       rf"{'false' if noel else 'true'}>")
+            else:                # jbf_fast_kernel<WIN, PX, BX, BY, CACHE, CSKIP>
+                pat = rf"jbf_fast_kernel<{w}, {npx}, {bx}, {by}, {cache}, (true|false)>"
+        c = [k for k in pj["kernels"] if re.search(pat, k["kernel"])]
         if not c:
-            return None, "no K1 entry for this window in the profile"
+            return None, "no K1 entry for this kernel in the profile"
         return max(c, key=lambda k: k["grid"]), os.path.relpath(path, ROOT)
     except Exception as e:          # no profile: the live figures stand alone
         return None, f"no profile ({type(e).__name__})"
@@ -365,7 +377,7 @@ def main():
 
     # from an idle GPU first (the W + K contract by itself), then at the clock the GPU holds under load (the headline)
     idle = None
-    if args.wakeup_ms > 0:
+    if args.wakeup_ms > 0 and not args.no_idle_leg:
         dt_i, _, k1_i, _ = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, 0.0)
         dt_i = sharding.allreduce_max(dt_i)
         idle = {"value": total_frames * W * H * args.steps / dt_i / 1e6, "ms_per_step": dt_i / args.steps * 1e3,
@@ -378,7 +390,9 @@ def main():
     if rank == 0:
         px_per_launch = count * W * H
         k1_avg_ms = float(np.mean(k1_ms))
-        entry, src = pmc_lookup(args.pmc_json, p.window_size)
+        names = filters.JointBilateralFilter.variants()
+        vname = names[args.variant] if args.variant >= 0 else next((nm for nm in names[1:] if nm.startswith(f"w{p.window_size}-")), None)
+        entry, src = pmc_lookup(args.pmc_json, p.window_size, vname)
         roof = {"bound": "hbm", "bound_measured": "valu-issue",
                 "limiter": "valu-issue (K1 does 2 exp + ~30 flops per tap against 11 B/pixel; see roofline.valu)",
                 "kernel": "K1 joint_bilateral_filtering"}
@@ -402,7 +416,7 @@ def main():
                 "frames_per_gpu": count, "width": W, "height": H, "window": p.window_size,
                 "sharding": f"contiguous frame blocks x{world}, params broadcast from rank 0 ({args.backend if use_dist else 'single process'}"
                             + (", all ranks on cuda:0" if args.share_device else "") + ")" + (" [REPLICAS ONLY]" if replicas_only else ""),
-                "kernel_variant": filters.JointBilateralFilter.variants()[args.variant] if args.variant >= 0 else "auto",
+                "kernel_variant": (names[args.variant] if args.variant >= 0 else f"auto ({vname})"),
             },
             "roofline": roof,
             "checksum": {"sum_filtered_mm": checksum[0], "frames": int(checksum[1])},
@@ -439,7 +453,9 @@ def side_measurements(torch, filters, synth, args):
         dt, k0, k1, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 2, lambda: None)
         px = n * w * h
         k1m = float(np.mean(k1))
-        entry, src = pmc_lookup(args.pmc_json, window)
+        names = filters.JointBilateralFilter.variants()
+        vname = names[args.variant] if args.variant >= 0 else next((nm for nm in names[1:] if nm.startswith(f"w{window}-")), None)
+        entry, src = pmc_lookup(args.pmc_json, window, vname)
         out[name] = {"workload": f"K0 + K1 on {n} x {w}x{h}, window {window}, sigma {ss:g}/{cs:g}/{ds:g}",
                      "frames": n, "width": w, "height": h, "window": window,
                      "process_mpix_s": px * steps / dt / 1e6, "k1_mpix_s": px / (k1m * 1e-3) / 1e6,
