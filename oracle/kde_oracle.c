@@ -547,11 +547,25 @@ void okde_jbf_stage(int width, int height, const float* depth, const uint8_t* gu
                         }
                 }
                 if (grid1 || (dens[1] > 0.0 && dens[1] < 0x1p-110)) {
-                    /* sums on the float32 denormal grid: bracket the quantisation noise of the weights (see quantised()) */
+                    /* Sums on the float32 denormal grid.  The float32 code holds every weight AND every product d * weight
+                     * as a whole number of grid units (2^-149): bracket the quantisation of the weights (see quantised())
+                     * and, on top, of the numerator's terms -- half a unit each, i.e. 0.5 n / (sum of weights in units) in
+                     * the result (a hole whose single surviving weight is 0.77 units comes out as round(d): found by
+                     * tools/stress_parity.py, seed 204 case 192). */
                     flag |= OKDE_STAGE_BAND | OKDE_STAGE_GRID;
-                    for (int q = -1; q <= 1; q += 2) {
+                    int nq = 0;                  /* taps whose float32 weight can be a non-zero number of units */
+                    for (int k = 0; k < t.n; k++) nq += t.base[k] >= 0x1p-151;
+                    for (int q = -1; q <= 1; q++) {
                         int dummy = 0;
-                        env_add(&e, jbf_eval64(&t, dden, don, 0.0, 1.0, 1.0, &dummy, NULL, 0, 0.0, q, fin, NULL, 0.0, NULL, &a));
+                        double dq[2] = {0.0, 0.0};
+                        const double r = jbf_eval64(&t, dden, don, 0.0, 1.0, 1.0, &dummy, NULL, 0, 0.0, q, fin, dq, 0.0, NULL, &a);
+                        if (dq[1] > 0.0) {
+                            const double slack = 0.5 * kUnit * (double)nq / dq[1];
+                            env_add(&e, r - slack > 0.0 ? r - slack : 0.0);
+                            env_add(&e, r + slack);
+                        } else {
+                            env_add(&e, r);
+                        }
                     }
                     e.zero = 1;
                 }
@@ -1485,13 +1499,22 @@ void okde_ers_stage(int width, int height, const float* rd, const uint8_t* bgr, 
                         }
                 }
                 if ((grid1 || (dens[1] > 0.0 && dens[1] < 0x1p-110)) && fin == fin) {
+                    /* sums on the float32 denormal grid: weights and numerator terms are whole grid units (see okde_jbf_stage) */
                     flag |= OKDE_STAGE_BAND | OKDE_STAGE_GRID;
-                    for (int q = -1; q <= 1; q += 2) {
+                    for (int q = -1; q <= 1; q++) {
                         int dummy = 0;
+                        double dq[2] = {0.0, 0.0};
                         const double r = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &dummy, NULL, 0,
-                                                    0.0, q, fin, NULL, 0.0, NULL, &a);
-                        if (r != r) nan_seen = 1;
-                        else env_add(&e, r);
+                                                    0.0, q, fin, dq, 0.0, NULL, &a);
+                        if (r != r) {
+                            nan_seen = 1;
+                        } else if (dq[1] > 0.0) {
+                            const double slack = 0.5 * kUnit * (double)t.n / dq[1];      /* (n: every valid tap, an upper bound) */
+                            env_add(&e, r - slack > 0.0 ? r - slack : 0.0);
+                            env_add(&e, r + slack);
+                        } else {
+                            env_add(&e, r);
+                        }
                     }
                     e.zero = 1;
                 }

@@ -220,6 +220,24 @@ def test_weights_of_the_last_denormal_unit_are_kept(torch_cuda, F, oracle):
             assert_k1_stagewise(jbf.params, depth, bgr, got, variant=v, what=f"last denormal unit, variant {nm} window {win}", band_max=0.1)
 
 
+def test_weights_below_one_denormal_unit_fixture(torch_cuda, F, oracle):
+    """tests/golden/k1_grid_numerator.npz (stress seed 204, case 192): holes whose surviving weights are below one unit of the
+    float32 denormal grid.  The generic kernel (float32 arithmetic like the reference's) returns round(d) there, the tuned
+    kernels (weights at 2^24 scale) the unquantised mean; both lie in the GRID interval of the stage-wise check."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "k1_grid_numerator.npz"))
+    win, ss, cs, ds = z["params"]
+    depth, bgr = z["depth"], z["bgr"]
+    h, w = depth.shape
+    for v in (-1, 0):
+        p = params(F, int(win), float(ss), float(cs), float(ds), pre=0)
+        jbf = F.JointBilateralFilter(w, h, p)
+        jbf.set_variant(v)
+        out = torch_cuda.empty((1, h, w), dtype=torch_cuda.float32, device="cuda")
+        jbf.filter_batch(dev(torch_cuda, depth[None]), dev(torch_cuda, bgr[None]), out)
+        r = assert_k1_stagewise(p, depth, bgr, host(out)[0], variant=v, what=f"sub-unit weights, variant {v}", band_max=0.2)
+        assert r["grid"] >= 2
+
+
 def test_non_finite_and_huge_depth_samples(torch_cuda, F, oracle, frame):
     """What is guaranteed for depth values no sensor produces (input domain).  A tap of +inf or of
     3e38 mm is "valid" (> 50) in the reference and turns its window into NaN / inf / 1e37.  (a) The reference-shaped

@@ -95,3 +95,22 @@ def test_k10_restatement_passes_its_own_stage_check(oracle, synth, frame, case):
         st2 = oracle.ers_stage(rd9, bgr, rl, avg_in=st.avg32, dev_in=dev)
         assert not np.isnan(st2.fin64[np.isnan(out)]).any()
         assert oracle.stage_check(out, st2)["bad_dev"] >= np.isnan(out).sum()      # ... and that deviation is rejected
+
+
+def test_k1_stage_grid_pixels_allow_the_quantised_numerator(oracle):
+    """Found by tools/stress_parity.py (seed 204, case 192; tests/golden/k1_grid_numerator.npz is a crop of it): a hole whose
+    neighbours all differ from it by cd ~ 8e4 at sigma_c 20 has weights below ONE unit of the float32 denormal grid; the
+    float32 code holds the single surviving weight as 1 unit and the product d * weight as round(d) units, so it returns
+    round(d) -- 1849.0 where the binary64 value is 1848.53.  Such pixels are GRID: the interval brackets the quantisation
+    of the weights and of the numerator's terms (half a unit each)."""
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "k1_grid_numerator.npz"))
+    win, ss, cs, ds = z["params"]
+    out = oracle.jbf_kernel(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds))
+    st = oracle.jbf_stage(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds))
+    assert out[7, 0] == 1849.0 and out[10, 0] == 1853.0                      # whole millimetres: the quantised numerator
+    for y in (7, 10):
+        assert st.flags[y, 0] & oracle.Stage.GRID and st.lo[y, 0] < out[y, 0] < st.hi[y, 0]
+        assert st.hi[y, 0] - st.lo[y, 0] < 4.0                               # ... and the interval stays a few units wide
+    assert not oracle.stage_check(out, st)["bad"].any()
