@@ -211,7 +211,7 @@ static double n_significant(const double* w, const uint8_t* use, int n, double t
  * caller is going to probe (widens the threshold band, see thr_band); *tol_out: that band's half-width. */
 static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double avg_rel, double thr_scale,
                          double und_scale, int* band, double* n_eff, int q1, double centre1, int q2, double centre2,
-                         double* den_out, double band_eps, double* tol_out, const double* avg_abs)
+                         double* den_out, double band_eps, double* tol_out, const double* avg_abs, double* wout)
 {
     const double U = kUnder * und_scale;
     double wa = 0.0, wt = 0.0;
@@ -224,22 +224,25 @@ static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double av
         wt += f;
     }
     if (den_out) den_out[0] = wt, den_out[1] = 0.0;
-    if (!(wt > 0.0)) return 0.0;
+    if (!avg_abs && !(wt > 0.0)) return 0.0;      /* (with a GIVEN average pass 2 does not depend on pass 1's sums) */
     if (n_eff) *n_eff = n_significant(t->base, NULL, t->n, wt, U);
-    const double tol = depth_on ? thr_band(band_eps, wa / wt, dden) : 1.5e-4;
+    const double tol = (depth_on && !avg_abs) ? thr_band(band_eps, wa / wt, dden) : 1.5e-4;
     if (tol_out) *tol_out = tol;
     wa = avg_abs ? *avg_abs : wa / wt * (1.0 + avg_rel);      /* avg_abs: the stage-wise check evaluates pass 2 at a GIVEN average */
     double nu = 0.0, de = 0.0;
     for (int k = 0; k < t->n; k++) {
         double f = t->base[k];
+        if (wout) wout[k] = f;           /* (a tap below the underflow point: its exact weight, for the GRID class) */
         if (f <= U) continue;
         if (depth_on) {
             const double xd = (t->d[k] - wa) * (t->d[k] - wa) / dden;
             if (fabs(xd / kXZ - 1.0) <= tol) *band |= 1;
             if (xd < kXZ * thr_scale) f *= exp(-xd);
             if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
+            if (wout) wout[k] = f;
             if (f <= U) continue;
         }
+        if (wout) wout[k] = f;
         f = quantised(f, t->d[k], centre2, q2);
         nu += t->d[k] * f;
         de += f;
@@ -354,13 +357,13 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                 int band = 0;
                 double n_eff = 1.0, dens[2] = {0.0, 0.0};
                 double tol = 1.5e-4;
-                const double r0 = jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL, NULL);
+                const double r0 = jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL, NULL, NULL);
                 /* rounding of the float32 sums behind the average: the first-order bound of recursive summation over
                  * the taps that can round at all (see n_significant), plus the products and the division */
                 const double eps_avg = (4.0 + 0.5 * n_eff) * 1.1920928955078125e-7;
                 env_add(&e, r0);
-                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol, NULL));
-                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, -eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol, NULL));
+                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol, NULL, NULL));
+                env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, -eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol, NULL, NULL));
                 if (band) {
                     flag |= 2;
                     for (int a = -1; a <= 1; a++)
@@ -368,7 +371,7 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                             for (int c = -1; c <= 1; c++) {
                                 int dummy = 0;
                                 env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, a * eps_avg, 1.0 + b * tol,
-                                                       1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, NULL));
+                                                       1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, NULL, NULL));
                             }
                 }
                 /* a sum of weights so small that the 2^-149 grid is within 1e-6 of it: the float32 value is
@@ -380,7 +383,7 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                         for (int b = (qb ? -1 : 0); b <= (qb ? 1 : 0); b++) {
                             if (a == 0 && b == 0) continue;
                             int dummy = 0;
-                            env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &dummy, NULL, a, wa0, b, r0, NULL, 0.0, NULL, NULL));
+                            env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &dummy, NULL, a, wa0, b, r0, NULL, 0.0, NULL, NULL, NULL));
                         }
                 }
                 env_add(&e, (double)out);
@@ -410,6 +413,66 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
  * Only pixels with a tap ON a Q1 decision at that very average (BAND), or whose sums of weights lie on the float32
  * denormal grid (GRID), get an interval instead: both outcomes of the open decision, evaluated at the same average.
  * ---------------------------------------------------------------------------------------- */
+/* GRID class of the stage-wise check: sums of weights on the float32 denormal grid (2^-149 = one unit u).  A faithful
+ * float32 evaluation holds every weight and every product d * weight as a whole number of units, and a colour factor
+ * that is itself a denormal is rounded to the grid BEFORE it is multiplied by S: a tap whose exact weight is 0.4 u can
+ * survive as 1 u (exp(-x) = 0.67 u -> 1 u, times S = 0.61 -> 0.61 u -> 1 u) while its neighbours at 0.25 u vanish, and the
+ * pixel comes out as round(d) of that one tap (tools/stress_parity.py seed 208 case 4866, seed 204 case 192).  So: every
+ * tap with an exact weight above u / 16 may end anywhere in [max(0, w - 2u), w + 2u], independently of the others, and the
+ * numerator is off by up to half a unit per surviving tap.  lo / hi = the extremes of (sum d w' +- 0.5 u n') / sum w' over
+ * that box (fixed-point iteration: raise the taps above the current value, lower those below); *zero = the sum of the
+ * weights can vanish altogether. */
+static const double kTinyW = 0x1p-153;
+static void grid_extremes(const double* d, const double* w, int n, double* lo, double* hi, int* zero)
+{
+    int cand = 0, all_can_vanish = 1;
+    double dmax = 0.0, dmin = 0.0;
+    for (int k = 0; k < n; k++) {
+        if (!(w[k] > kTinyW)) continue;
+        if (!cand || d[k] > dmax) dmax = d[k];
+        if (!cand || d[k] < dmin) dmin = d[k];
+        cand++;
+        if (w[k] - 2.0 * kUnit > 0.0) all_can_vanish = 0;
+    }
+    *zero = all_can_vanish;
+    *lo = *hi = 0.0;
+    if (!cand) return;
+    for (int side = 0; side < 2; side++) {          /* 0: highest admissible value, 1: lowest */
+        double sw = 0.0, sdw = 0.0;
+        for (int k = 0; k < n; k++)
+            if (w[k] > kTinyW) sw += w[k], sdw += d[k] * w[k];
+        double r = sdw / sw;
+        for (int it = 0; it < n + 4; it++) {
+            double a = 0.0, b = 0.0;
+            int np = 0;
+            for (int k = 0; k < n; k++) {
+                if (!(w[k] > kTinyW)) continue;
+                const int raise = side == 0 ? d[k] > r : d[k] < r;
+                double wk = raise ? w[k] + 2.0 * kUnit : w[k] - 2.0 * kUnit;
+                if (!(wk > 0.0)) continue;
+                a += d[k] * wk;
+                b += wk;
+                np++;
+            }
+            double rn;
+            if (b > 0.0) {
+                /* (a surviving float32 weight is at least one unit: the numerator's half units are relative to >= 1 u) */
+                const double s = 0.5 * kUnit * (double)np, bb = b > kUnit ? b : kUnit;
+                rn = side == 0 ? a / b + s / bb : a / b - s / bb;
+                if (rn < 0.0) rn = 0.0;
+            } else {                                    /* everything lowered away: the extreme tap alone survives, as 1 u */
+                rn = side == 0 ? dmax + 0.5 : dmin - 0.5;
+                if (rn < 0.0) rn = 0.0;
+            }
+            const int done = side == 0 ? !(rn > r * (1.0 + 1e-15)) : !(rn < r * (1.0 - 1e-15));
+            r = side == 0 ? (rn > r ? rn : r) : (rn < r ? rn : r);
+            if (done) break;
+        }
+        if (side == 0) *hi = r;
+        else *lo = r;
+    }
+}
+
 static void jbf_collect_taps(int width, int height, const float* depth, const uint8_t* guide, const float* spatial,
                              int window_size, float color_sigma, int x, int y, jbf_taps* t)
 {
@@ -513,21 +576,24 @@ void okde_jbf_stage(int width, int height, const float* depth, const uint8_t* gu
             if (out->avg32) out->avg32[p] = a32;
             double avg64 = 0.0, tol_avg = INFINITY;
             const int grid1 = wt > 0.0 && wt < 0x1p-110;
+            int sub1 = 0;                /* a tap below the underflow point that a float32 evaluation may still hold (GRID) */
+            for (int k = 0; k < t.n; k++) sub1 |= t.base[k] > kTinyW && t.base[k] <= kUnder;
+            const int open1 = band1 || (sub1 && !(wt >= 0x1p-110));      /* "is there any weight at all" is not decided */
             if (wt > 0.0) {
                 avg64 = wa / wt;
-                if (!band1 && !grid1) tol_avg = avg_bound(t.d, t.base, NULL, t.n, kUnder, wt, avg64);
+                if (!open1 && !grid1) tol_avg = avg_bound(t.d, t.base, NULL, t.n, kUnder, wt, avg64);
             }
             if (out->avg64) out->avg64[p] = avg64;
             if (out->avg_tol) out->avg_tol[p] = tol_avg;
             env_acc e = {0.0, 0.0, 0, 0};
             double fin = 0.0;
-            if (!(wt > 0.0) && !band1) {
+            if (!(wt > 0.0) && !open1) {
                 /* no weight at all: the output is 0 (.cu:39) and there is no average */
                 flag |= OKDE_STAGE_NOWEIGHT;
                 if (a32 == a32) flag |= OKDE_STAGE_MISMATCH;
             } else if (a32 != a32) {
-                /* the implementation saw no weight; admissible only when a weight sits on the underflow decision */
-                if (band1) flag |= OKDE_STAGE_BAND | OKDE_STAGE_ZERO_OK;
+                /* the implementation saw no weight; admissible only when that decision is open */
+                if (open1) flag |= OKDE_STAGE_BAND | OKDE_STAGE_ZERO_OK | (sub1 ? OKDE_STAGE_GRID : 0);
                 else flag |= OKDE_STAGE_MISMATCH;
                 e.zero = 1;
             } else {
@@ -535,7 +601,8 @@ void okde_jbf_stage(int width, int height, const float* depth, const uint8_t* gu
                 const double a = (double)a32;
                 int band2 = 0;
                 double dens[2] = {0.0, 0.0}, tol = 1.5e-4;
-                fin = jbf_eval64(&t, dden, don, 0.0, 1.0, 1.0, &band2, NULL, 0, 0.0, 0, 0.0, dens, 0.0, &tol, &a);
+                double w2[OKDE_MAXTAPS];
+                fin = jbf_eval64(&t, dden, don, 0.0, 1.0, 1.0, &band2, NULL, 0, 0.0, 0, 0.0, dens, 0.0, &tol, &a, w2);
                 env_add(&e, fin);
                 if (band1 || band2) {
                     flag |= OKDE_STAGE_BAND;
@@ -543,31 +610,20 @@ void okde_jbf_stage(int width, int height, const float* depth, const uint8_t* gu
                         for (int c = -1; c <= 1; c++) {
                             int dummy = 0;
                             env_add(&e, jbf_eval64(&t, dden, don, 0.0, 1.0 + b * tol, 1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0,
-                                                   0.0, NULL, 0.0, NULL, &a));
+                                                   0.0, NULL, 0.0, NULL, &a, NULL));
                         }
                 }
-                if (grid1 || (dens[1] > 0.0 && dens[1] < 0x1p-110)) {
-                    /* Sums on the float32 denormal grid.  The float32 code holds every weight AND every product d * weight
-                     * as a whole number of grid units (2^-149): bracket the quantisation of the weights (see quantised())
-                     * and, on top, of the numerator's terms -- half a unit each, i.e. 0.5 n / (sum of weights in units) in
-                     * the result (a hole whose single surviving weight is 0.77 units comes out as round(d): found by
-                     * tools/stress_parity.py, seed 204 case 192). */
+                if (grid1 || open1 || (dens[1] > 0.0 && dens[1] < 0x1p-110)) {
+                    /* sums on the float32 denormal grid: see grid_extremes() */
                     flag |= OKDE_STAGE_BAND | OKDE_STAGE_GRID;
-                    int nq = 0;                  /* taps whose float32 weight can be a non-zero number of units */
-                    for (int k = 0; k < t.n; k++) nq += t.base[k] >= 0x1p-151;
-                    for (int q = -1; q <= 1; q++) {
-                        int dummy = 0;
-                        double dq[2] = {0.0, 0.0};
-                        const double r = jbf_eval64(&t, dden, don, 0.0, 1.0, 1.0, &dummy, NULL, 0, 0.0, q, fin, dq, 0.0, NULL, &a);
-                        if (dq[1] > 0.0) {
-                            const double slack = 0.5 * kUnit * (double)nq / dq[1];
-                            env_add(&e, r - slack > 0.0 ? r - slack : 0.0);
-                            env_add(&e, r + slack);
-                        } else {
-                            env_add(&e, r);
-                        }
+                    double glo, ghi;
+                    int gz;
+                    grid_extremes(t.d, w2, t.n, &glo, &ghi, &gz);
+                    if (ghi > 0.0) {
+                        env_add(&e, ghi);
+                        if (glo > 0.0) env_add(&e, glo);
                     }
-                    e.zero = 1;
+                    if (gz || !(glo > 0.0)) e.zero = 1;
                 }
             }
             if (!e.nonzero) e.lo = e.hi = 0.0;
@@ -1125,7 +1181,7 @@ typedef struct {
  * Returns the result (0 = "output is 0", NaN = the Q6 quirk); *band |= 1 when a tap sits in a decision band. */
 static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, int depth_on, float a, double avg_rel,
                          double thr_scale, double und_scale, int* band, double* n_eff, int q1, double centre1, int q2,
-                         double centre2, double* den_out, double band_eps, double* tol_out, const double* avg_abs)
+                         double centre2, double* den_out, double band_eps, double* tol_out, const double* avg_abs, double* wout)
 {
     const double U = kUnder * und_scale;
     double wa = 0.0, wt = 0.0;
@@ -1144,9 +1200,9 @@ static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, i
         wt += f;
     }
     if (den_out) den_out[0] = wt, den_out[1] = 0.0;
-    if (!(wt > 0.0)) return 0.0;
+    if (!avg_abs && !(wt > 0.0)) return 0.0;
     if (n_eff) *n_eff = n_significant(w1, NULL, t->n, wt, 0.0);
-    const double tol = depth_on ? thr_band(band_eps, wa / wt, dden) : 1.5e-4;     /* see jbf_eval64 */
+    const double tol = (depth_on && !avg_abs) ? thr_band(band_eps, wa / wt, dden) : 1.5e-4;     /* see jbf_eval64 */
     if (tol_out) *tol_out = tol;
     wa = avg_abs ? *avg_abs : wa / wt * (1.0 + avg_rel);      /* avg_abs: see jbf_eval64 */
     float cs = color_sigma_in;
@@ -1166,6 +1222,7 @@ static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, i
             if (xd < kXZ * thr_scale) f *= exp(-xd);
         }
         if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
+        if (wout) wout[k] = f;
         if (f <= U) continue;            /* NaN fails the test and is summed in, as in float32 */
         if (f == f) f = quantised(f, t->d[k], centre2, q2);
         nu += t->d[k] * f;
@@ -1300,11 +1357,11 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                 int band = 0;
                 double n_eff = 1.0, dens[2] = {0.0, 0.0};
                 double tol = 1.5e-4;
-                const double r0 = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL, NULL);
+                const double r0 = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL, NULL, NULL);
                 const double eps_avg = (4.0 + 0.5 * n_eff) * 1.1920928955078125e-7;     /* as in okde_jbf_kernel */
                 for (int v = 0; v < nalt; v++)
                     for (int a = -1; a <= 1; a++) {
-                        const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol, NULL);
+                        const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg, 1.0, 1.0, &band, NULL, 0, 0.0, 0, 0.0, NULL, eps_avg, &tol, NULL, NULL);
                         if (r != r) nan_ok = 1;
                         else env_add(&e, r);
                     }
@@ -1316,7 +1373,7 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                                 for (int c = -1; c <= 1; c++) {
                                     int dummy = 0;
                                     const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg,
-                                                                1.0 + b * tol, 1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, NULL);
+                                                                1.0 + b * tol, 1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, NULL, NULL);
                                     if (r != r) nan_ok = 1;
                                     else env_add(&e, r);
                                 }
@@ -1328,7 +1385,7 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                         for (int b = (qb ? -1 : 0); b <= (qb ? 1 : 0); b++) {
                             if (a == 0 && b == 0) continue;
                             int dummy = 0;
-                            const double r = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &dummy, NULL, a, r0, b, r0, NULL, 0.0, NULL, NULL);
+                            const double r = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &dummy, NULL, a, r0, b, r0, NULL, 0.0, NULL, NULL, NULL);
                             if (r != r) nan_ok = 1;
                             else env_add(&e, r);
                         }
@@ -1429,7 +1486,7 @@ void okde_ers_stage(int width, int height, const float* rd, const uint8_t* bgr, 
             uint8_t flag = 0;
             /* ---- pass 1 in binary64 (same-label taps) ---- */
             double w1[OKDE_MAXTAPS];
-            int band1 = 0, count = 0;
+            int band1 = 0, count = 0, sub1 = 0;
             double wa = 0.0, wt = 0.0;
             for (int k = 0; k < t.n; k++) {
                 w1[k] = 0.0;
@@ -1439,6 +1496,7 @@ void okde_ers_stage(int width, int height, const float* rd, const uint8_t* bgr, 
                 if (color_sigma_in != 0.0f && expf(-t.cd[k] / (2 * (color_sigma_in * color_sigma_in))) != 0.0f)
                     f *= exp(-(double)t.cd[k] / cden);
                 if (fabs(f / kUnder - 1.0) <= 5e-4) band1 = 1;
+                if (f > kTinyW && f <= kUnder) sub1 = 1;
                 if (f <= kUnder) continue;
                 w1[k] = f;
                 wa += t.d[k] * f;
@@ -1455,20 +1513,21 @@ void okde_ers_stage(int width, int height, const float* rd, const uint8_t* bgr, 
             if (out->dev32) out->dev32[p] = dev32;
             double avg64 = 0.0, tol_avg = INFINITY;
             const int grid1 = wt > 0.0 && wt < 0x1p-110;
+            const int open1 = band1 || (sub1 && !(wt >= 0x1p-110));      /* "is there any weight at all" is not decided */
             if (wt > 0.0) {
                 avg64 = wa / wt;
-                if (!band1 && !grid1) tol_avg = avg_bound(t.d, w1, t.same, t.n, 0.0, wt, avg64);
+                if (!open1 && !grid1) tol_avg = avg_bound(t.d, w1, t.same, t.n, 0.0, wt, avg64);
             }
             if (out->avg64) out->avg64[p] = avg64;
             if (out->avg_tol) out->avg_tol[p] = tol_avg;
             env_acc e = {0.0, 0.0, 0, 0};
             double fin = 0.0, dev64 = 0.0, tol_dev = INFINITY;
             int nan_seen = 0;
-            if (!(wt > 0.0) && !band1) {
+            if (!(wt > 0.0) && !open1) {
                 flag |= OKDE_STAGE_NOWEIGHT;
                 if (a32 == a32) flag |= OKDE_STAGE_MISMATCH;
             } else if (a32 != a32) {
-                if (band1) flag |= OKDE_STAGE_BAND | OKDE_STAGE_ZERO_OK;
+                if (open1) flag |= OKDE_STAGE_BAND | OKDE_STAGE_ZERO_OK | (sub1 ? OKDE_STAGE_GRID : 0);
                 else flag |= OKDE_STAGE_MISMATCH;
                 e.zero = 1;
             } else {
@@ -1483,8 +1542,10 @@ void okde_ers_stage(int width, int height, const float* rd, const uint8_t* bgr, 
                 const float adaptive = (float)(5.0 * (double)dev32 / (double)(a32 * a32));
                 int band3 = 0;
                 double dens[2] = {0.0, 0.0}, tol = 1.5e-4;
+                double w3[OKDE_MAXTAPS];
+                for (int k = 0; k < t.n; k++) w3[k] = 0.0;
                 fin = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band3, NULL, 0, 0.0, 0, 0.0, dens,
-                                 0.0, &tol, &a);
+                                 0.0, &tol, &a, w3);
                 if (fin != fin) nan_seen = 1;
                 else env_add(&e, fin);
                 if (band1 || band3) {
@@ -1493,30 +1554,22 @@ void okde_ers_stage(int width, int height, const float* rd, const uint8_t* bgr, 
                         for (int c = -1; c <= 1; c++) {
                             int dummy = 0;
                             const double r = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0 + b * tol,
-                                                        1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, &a);
+                                                        1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, &a, NULL);
                             if (r != r) nan_seen = 1;
                             else env_add(&e, r);
                         }
                 }
-                if ((grid1 || (dens[1] > 0.0 && dens[1] < 0x1p-110)) && fin == fin) {
-                    /* sums on the float32 denormal grid: weights and numerator terms are whole grid units (see okde_jbf_stage) */
+                if ((grid1 || open1 || (dens[1] > 0.0 && dens[1] < 0x1p-110)) && fin == fin) {
+                    /* sums on the float32 denormal grid: see grid_extremes() */
                     flag |= OKDE_STAGE_BAND | OKDE_STAGE_GRID;
-                    for (int q = -1; q <= 1; q++) {
-                        int dummy = 0;
-                        double dq[2] = {0.0, 0.0};
-                        const double r = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &dummy, NULL, 0,
-                                                    0.0, q, fin, dq, 0.0, NULL, &a);
-                        if (r != r) {
-                            nan_seen = 1;
-                        } else if (dq[1] > 0.0) {
-                            const double slack = 0.5 * kUnit * (double)t.n / dq[1];      /* (n: every valid tap, an upper bound) */
-                            env_add(&e, r - slack > 0.0 ? r - slack : 0.0);
-                            env_add(&e, r + slack);
-                        } else {
-                            env_add(&e, r);
-                        }
+                    double glo, ghi;
+                    int gz;
+                    grid_extremes(t.d, w3, t.n, &glo, &ghi, &gz);
+                    if (ghi > 0.0) {
+                        env_add(&e, ghi);
+                        if (glo > 0.0) env_add(&e, glo);
                     }
-                    e.zero = 1;
+                    if (gz || !(glo > 0.0)) e.zero = 1;
                 }
             }
             if (!e.nonzero) e.lo = e.hi = 0.0;

@@ -102,7 +102,8 @@ def test_k1_stage_grid_pixels_allow_the_quantised_numerator(oracle):
     neighbours all differ from it by cd ~ 8e4 at sigma_c 20 has weights below ONE unit of the float32 denormal grid; the
     float32 code holds the single surviving weight as 1 unit and the product d * weight as round(d) units, so it returns
     round(d) -- 1849.0 where the binary64 value is 1848.53.  Such pixels are GRID: the interval brackets the quantisation
-    of the weights and of the numerator's terms (half a unit each)."""
+    of the weights (each tap independently within two units of its exact weight, see grid_extremes() in kde_oracle.c) and of
+    the numerator's terms (half a unit each)."""
     import os
     from conftest import GOLDEN
     z = np.load(os.path.join(GOLDEN, "k1_grid_numerator.npz"))
@@ -112,5 +113,32 @@ def test_k1_stage_grid_pixels_allow_the_quantised_numerator(oracle):
     assert out[7, 0] == 1849.0 and out[10, 0] == 1853.0                      # whole millimetres: the quantised numerator
     for y in (7, 10):
         assert st.flags[y, 0] & oracle.Stage.GRID and st.lo[y, 0] < out[y, 0] < st.hi[y, 0]
-        assert st.hi[y, 0] - st.lo[y, 0] < 4.0                               # ... and the interval stays a few units wide
+        assert st.hi[y, 0] - st.lo[y, 0] < 12.0                              # ... the span of the few taps that may survive
     assert not oracle.stage_check(out, st)["bad"].any()
+
+
+def test_k1_stage_sub_unit_weights_that_survive_by_double_rounding(oracle):
+    """tools/stress_parity.py seed 208 case 4866 (crop: tests/golden/k1_subunit_double_rounding.npz): a hole at window 3 whose
+    three valid neighbours have exact weights of 0.25 / 0.41 / 0.25 denormal units -- all below the float32 underflow point
+    2^-150.  The float32 code still fills it: exp(-x) = 0.67 u rounds to 1 u, times S = 0.61 is 0.61 u and rounds to 1 u
+    again, while the diagonal neighbours (S = 0.37) vanish; the output is round(d) of that one tap.  The stage check must
+    not call this "no weight": such pixels are GRID, 0 and every value the surviving taps can produce are admissible."""
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "k1_subunit_double_rounding.npz"))
+    win, ss, cs, ds = z["params"]
+    out = oracle.jbf_kernel(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds))
+    st = oracle.jbf_stage(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds))
+    assert out[4, 5] == 2691.0 and z["depth"][4, 5] == 0.0
+    f = st.flags[4, 5]
+    assert f & oracle.Stage.GRID and f & oracle.Stage.ZERO_OK and not f & (oracle.Stage.NOWEIGHT | oracle.Stage.MISMATCH)
+    assert st.lo[4, 5] <= 2691.0 <= st.hi[4, 5]
+    assert not oracle.stage_check(out, st)["bad"].any()
+    # an implementation that flushes those weights (the tuned kernels' 2^24 scale: exact weight < 2^-150 -> 0) reports no
+    # weight and writes 0: admissible as well
+    avg = st.avg32.copy()
+    avg[4, 5] = np.nan
+    zero = out.copy()
+    zero[4, 5] = 0.0
+    st2 = oracle.jbf_stage(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds), avg_in=avg)
+    assert not oracle.stage_check(zero, st2)["bad"].any()
