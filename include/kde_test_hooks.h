@@ -16,6 +16,11 @@ extern "C" {
  * the empirical HBM ceiling bench.py quotes next to the 8 TB/s datasheet figure.  0 = ok. */
 int kde_bench_copy(const void* src_dev, void* dst_dev, size_t bytes, void* stream);
 
+/* packed-BGR copy of npix pixels with K0's access pattern (one unaligned dword load per pixel, 16-bit stores): run under the
+ * same PMC passes as K0 it calibrates FETCH_SIZE / WRITE_SIZE for that pattern (exactly 3 bytes read and written per
+ * pixel), which the 2 x FETCH_SIZE rule of 16-byte streams does not cover.  0 = ok. */
+int kde_bench_bgr3_copy(const void* src_dev, void* dst_dev, size_t npix, void* stream);
+
 /* out_dev[i] = the kernels' square root (csrc/kde_device_math.h, sqrt_int24) of the integer first + i
  * (i < n; first + n <= 2^24), so that the tests can prove it equal to sqrtf() on every argument calculateLD can
  * form (DepthAdaptiveSuperpixel.cu:213).  0 = ok. */

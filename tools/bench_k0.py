@@ -38,6 +38,16 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
     px = a.frames * a.width * a.height
+    # calibration launch for the PMC passes (tools/profile_round.sh): a packed-BGR copy with K0's access pattern that reads
+    # and writes exactly 3 bytes per pixel (tools/hooks, not product code)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kde_hooks", os.path.join(os.path.dirname(os.path.abspath(__file__)), "hooks", "hooks.py"))
+    hooks = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hooks)
+    for _ in range(3):
+        assert hooks.lib().kde_bench_bgr3_copy(color.data_ptr(), out.data_ptr(), px, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(-1)[: 3 * (px // 2 * 2 - 2)], color.view(-1)[: 3 * (px // 2 * 2 - 2)])
     print(json.dumps({"size": f"{a.width}x{a.height}x{a.frames}", "ms": ms, "mpix_s": px / ms / 1e3,
                       "algorithmic_bytes": 6.0 * px, "hbm_frac": 6.0 * px / (ms * 1e-3) / 8e12}))
 

@@ -19,6 +19,8 @@ def lib() -> C.CDLL:
         l.kde_bench_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         l.kde_test_sqrt_int24.restype = C.c_int
         l.kde_test_sqrt_int24.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        l.kde_bench_bgr3_copy.restype = C.c_int
+        l.kde_bench_bgr3_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         l.kde_test_fastdiv24.restype = C.c_int
         l.kde_test_fastdiv24.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = l

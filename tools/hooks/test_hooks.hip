@@ -30,7 +30,37 @@ __global__ __launch_bounds__(256) void fastdiv24_probe_kernel(kde::FastDiv24 f, 
     if (i < n) out[i] = kde::fastdiv24(xs[i], f);
 }
 
+// packed-BGR copy with K0's own access pattern (calibration of FETCH_SIZE / WRITE_SIZE for it: the guide calibrates those
+// counters for 16-byte-per-lane streams only): every thread reads its pixel pair as two unaligned dwords (3 payload
+// bytes each, as K0 stages its tile) and writes it as three 16-bit stores (as K0 writes its output)
+__global__ __launch_bounds__(256) void bgr3_copy_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t npix)
+{
+    const size_t pair = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t p0 = 2 * pair;
+    if (p0 + 1 >= npix) return;                       // (the last pixel's dword read would leave the buffer: skipped)
+    uint32_t a, b;
+    __builtin_memcpy(&a, src + p0 * 3, 4);
+    if (p0 + 2 < npix) __builtin_memcpy(&b, src + p0 * 3 + 3, 4);
+    else b = (uint32_t)src[p0 * 3 + 3] | ((uint32_t)src[p0 * 3 + 4] << 8) | ((uint32_t)src[p0 * 3 + 5] << 16);
+    a &= 0x00ffffffu;
+    b &= 0x00ffffffu;
+    uint16_t* oh = reinterpret_cast<uint16_t*>(dst + p0 * 3);
+    oh[0] = (uint16_t)(a & 0xffffu);
+    oh[1] = (uint16_t)((a >> 16) | ((b & 0xffu) << 8));
+    oh[2] = (uint16_t)(b >> 8);
+}
+
 }  // namespace
+
+extern "C" int kde_bench_bgr3_copy(const void* src_dev, void* dst_dev, size_t npix, void* stream)
+{
+    if (!src_dev || !dst_dev || (reinterpret_cast<uintptr_t>(dst_dev) & 1u)) return 1;
+    const size_t pairs = npix / 2;
+    if (pairs == 0) return 0;
+    hipLaunchKernelGGL(bgr3_copy_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const uint8_t*>(src_dev), reinterpret_cast<uint8_t*>(dst_dev), npix);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
 
 extern "C" int kde_test_fastdiv24(uint32_t d, uint64_t max_dividend, uint32_t n, const uint32_t* xs_dev, uint32_t* out_dev,
                                   uint32_t* m_sh_ok, void* stream)

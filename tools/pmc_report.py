@@ -42,7 +42,7 @@ def source_hash():
 
 
 def short(name):
-    name = re.sub(r"kde::\(anonymous namespace\)::", "", name)
+    name = re.sub(r"(kde::)?\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*$", "", name)
     return name
@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--algo", default="", help="JSON: {kernel-name substring: algorithmic bytes per launch}")
     ap.add_argument("--command", default="", help="the profiled command, recorded in the file")
-    ap.add_argument("--keep", default="jbf|presmooth|mrf|copy_kernel|enhance|edge_|calc_ld|analyze|sample_clusters|p2r|points_map|buf_|spdsr|moments|plane|jacobi",
+    ap.add_argument("--keep", default="jbf|presmooth|mrf|copy_kernel|bgr3_copy|enhance|edge_|calc_ld|analyze|sample_clusters|p2r|points_map|buf_|spdsr|moments|plane|jacobi",
                     help="regex of kernel names to keep")
     a = ap.parse_args()
     keep = re.compile(a.keep)

@@ -53,6 +53,28 @@ pmc_chain)
   echo '{"presmooth_kernel": 117964800}' > "$OUT/algo_k0.json"      # 6 B/pixel x 64 x 640x480
   python3 tools/pmc_report.py --dir "$OUT/pmc_k0" --out "$OUT/pmc_k0.json" --command "python3 tools/bench_k0.py --wakeup-ms 0" \
       --algo "$OUT/algo_k0.json" 2> "$OUT/pmc_k0.summary"
+  # K0 moves bytes with dword loads / 16-bit stores, for which FETCH_SIZE / WRITE_SIZE are not calibrated: the packed-BGR copy
+  # of the same run (exactly 3 B read + 3 B written per pixel with the same access pattern) gives the factors
+  python3 - "$OUT/pmc_k0.json" <<'PY'
+import json, sys
+path = sys.argv[1]
+d = json.load(open(path))
+cal = next((k for k in d["kernels"] if "bgr3_copy" in k["kernel"]), None)
+k0 = [k for k in d["kernels"] if "presmooth" in k["kernel"]]
+if cal and k0:
+    px = 64 * 640 * 480
+    fr = 3.0 * px / (cal["counters"]["FETCH_SIZE"] * 1024.0)      # true bytes per counted FETCH byte
+    fw = 3.0 * px / (cal["counters"]["WRITE_SIZE"] * 1024.0)
+    for k in k0:
+        c = k["counters"]
+        rd, wr = c["FETCH_SIZE"] * 1024.0 * fr, c["WRITE_SIZE"] * 1024.0 * fw
+        k["derived"].update(read_bytes_calibrated=round(rd, 1), write_bytes_calibrated=round(wr, 1),
+                            traffic_ratio_calibrated=round((rd + wr) / k["derived"].get("algorithmic_bytes", 6.0 * px), 4))
+    d["k0_access_pattern_calibration"] = {"bytes_per_FETCH_SIZE_byte": round(fr, 4), "bytes_per_WRITE_SIZE_byte": round(fw, 4),
+                                          "from": "bgr3_copy_kernel (tools/hooks): 3 B read + 3 B written per pixel, dword loads / 16-bit stores"}
+    json.dump(d, open(path, "w"), indent=1)
+    print("K0 calibrated:", d["k0_access_pattern_calibration"], [k["derived"].get("traffic_ratio_calibrated") for k in k0])
+PY
   pmc_passes pmc_mrf python3 tools/bench_mrf.py --wakeup-ms 0
   python3 tools/pmc_report.py --dir "$OUT/pmc_mrf" --out "$OUT/pmc_mrf.json" --command "python3 tools/bench_mrf.py --wakeup-ms 0" 2> "$OUT/pmc_mrf.summary"
   pmc_passes pmc_spdsr python3 tools/bench_spdsr.py --wakeup-ms 0
@@ -65,7 +87,8 @@ out = sys.argv[1]
 parts = [json.load(open(f"{out}/pmc_{t}.json")) for t in ("chain", "k0", "mrf", "spdsr")]
 merged = {"source": parts[0]["source"], "kernel_source_sha16": parts[0]["kernel_source_sha16"],
           "note": "every kernel of the path besides K1's headline workloads (pmc_bench.json); entries carry the command they were profiled under",
-          "fetch_correction_measured": parts[0].get("fetch_correction_measured"), "kernels": []}
+          "fetch_correction_measured": parts[0].get("fetch_correction_measured"),
+          "k0_access_pattern_calibration": parts[1].get("k0_access_pattern_calibration"), "kernels": []}
 for d in parts:
     for k in d["kernels"]:
         merged["kernels"].append(dict(k, workload=d["command"]))
