@@ -373,14 +373,20 @@ struct AnalyzeSet {
 };
 struct AnalyzeSets {
     AnalyzeSet s[2];
-    int nsets;          // blockIdx.z = frame * nsets + segmenter
+    int nsets;          // grid = frames x nsets x clusters
+    int band;
 };
 
 __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
                                                               const kde_float3* __restrict__ pts, AnalyzeSets sets,
                                                               const float* __restrict__ intr)
 {
-    const unsigned frame = blockIdx.z / (unsigned)sets.nsets, seg = blockIdx.z - frame * (unsigned)sets.nsets;
+    // 1-D grid of (frame, segmenter, cluster row, cluster column) walked in XCD bands: a cluster scans a 2w x 2h window, i.e.
+    // it overlaps its eight neighbours' windows by half -- neighbours now share one XCD's L2 (KDE_K8_NO_BAND_WALK: A/B switch)
+    const unsigned ncl = (unsigned)(g.rows * g.cols);
+    const unsigned gid = sets.band ? xcd_band_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned zz = gid / ncl, cid = gid - zz * ncl;
+    const unsigned frame = zz / (unsigned)sets.nsets, seg = zz - frame * (unsigned)sets.nsets;
     const size_t fpx = (size_t)frame * g.width * g.height, fk = (size_t)frame * g.rows * g.cols;
     bgr += fpx * 3;
     pts += fpx;
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const
     __shared__ float sf[3][256];   // X Y Z
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
-    const int cluster_id = blockIdx.y * g.cols + blockIdx.x;
+    const int cluster_id = (int)cid;
     const int rpx = g.wx * 2 / 16 + 1, rpy = g.wy * 2 / 16 + 1;
     const kde_superpixel m0 = mean[cluster_id];
 
@@ -615,13 +621,20 @@ int launch_dasp_calc_ld_dual(const DaspGeom& g, int n, const uint8_t* bgr, const
     return launch_calc_sets<2>(g, n, bgr, pts, sets, first, s);
 }
 
+static int analyze_band_walk()
+{
+    static const int v = getenv("KDE_K8_NO_BAND_WALK") == nullptr ? 1 : 0;
+    return v;
+}
+
 int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const int32_t* labels,
                         kde_superpixel* mean, kde_float3* centers, const float* intr_dev, hipStream_t s)
 {
     AnalyzeSets sets;
     sets.s[0] = sets.s[1] = AnalyzeSet{labels, mean, centers};
     sets.nsets = 1;
-    hipLaunchKernelGGL(analyze_clusters_kernel, dim3(g.cols, g.rows, 1), dim3(256), 0, s, g, bgr, pts, sets, intr_dev);
+    sets.band = analyze_band_walk();
+    hipLaunchKernelGGL(analyze_clusters_kernel, dim3(g.cols * g.rows), dim3(256), 0, s, g, bgr, pts, sets, intr_dev);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }
@@ -635,7 +648,8 @@ int launch_dasp_analyze_dual(const DaspGeom& g, int n, const uint8_t* bgr, const
     sets.s[0] = AnalyzeSet{labels_a, mean_a, centers_a};
     sets.s[1] = AnalyzeSet{labels_b, mean_b, centers_b};
     sets.nsets = 2;
-    hipLaunchKernelGGL(analyze_clusters_kernel, dim3(g.cols, g.rows, 2 * n), dim3(256), 0, s, g, bgr, pts, sets, intr_dev);
+    sets.band = analyze_band_walk();
+    hipLaunchKernelGGL(analyze_clusters_kernel, dim3((unsigned)(g.cols * g.rows * 2 * n)), dim3(256), 0, s, g, bgr, pts, sets, intr_dev);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }

@@ -151,6 +151,7 @@ struct PreDev {
     const float* lut;
     int width, height, n;
     int tiles_x, tiles_y;
+    int band_walk;          // tiles are walked in XCD bands (row-pair kernel)
 };
 
 constexpr int kPreBX = 16, kPreBY = 16;
@@ -203,7 +204,12 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
         slot_x[k] = i - slot_y[k] * LW;
     }
     const size_t last_pix = (size_t)a.n * a.width * a.height - 1;     // its 4-byte read would leave the buffer
-    auto fetch = [&](int t, uint32_t* pre) {
+    // Tile walk: linear index L (this workgroup's k-th tile is blockIdx.x + k * gridDim.x) -> tile xcd_band_id(L, total), so
+    // that each XCD works through a contiguous band of the tile list and horizontally adjacent tiles -- which share their
+    // halo columns and, being only 96 bytes wide, their 128-byte lines -- meet in ONE L2 (KDE_K0_BAND_WALK, see launch_presmooth)
+    auto tile_of = [&](int L) { return a.band_walk ? (int)xcd_band_id((unsigned)L, (unsigned)total) : L; };
+    auto fetch = [&](int L, uint32_t* pre) {
+        const int t = tile_of(L);
         const int frame_i = t / tiles_per_frame;
         const int tile = t - frame_i * tiles_per_frame;
         const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
@@ -231,7 +237,8 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
 
     uint32_t pre[NSLOT];
     if ((int)blockIdx.x < total) fetch(blockIdx.x, pre);
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    for (int L = blockIdx.x; L < total; L += gridDim.x) {
+        const int t = tile_of(L);
         const int frame_i = t / tiles_per_frame;
         const int tile = t - frame_i * tiles_per_frame;
         const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
         for (int k = 0; k < NSLOT; k++)
             if (tid + k * NT < LW * LH) sc[slot_y[k] * LP + slot_x[k]] = pre[k];
         __syncthreads();
-        if (t + (int)gridDim.x < total) fetch(t + gridDim.x, pre);
+        if (L + (int)gridDim.x < total) fetch(L + gridDim.x, pre);
 
         const int xb = x0 + tx * kPrePX, y = y0 + ty;
         if (xb >= a.width || y >= a.height) continue;
@@ -711,6 +718,8 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
     d.n = a.n;
     constexpr int kPX = kPrePxPerThread;
     const bool old_form = a.radius > 2 || !k0_use_2x2();
+    static const bool band = getenv("KDE_K0_NO_BAND_WALK") == nullptr;      // A/B switch for tools/bench_k0.py
+    d.band_walk = band ? 1 : 0;
     d.tiles_x = ceil_div(a.width, old_form ? kPreBX * kPX : kPre22TW);
     d.tiles_y = ceil_div(a.height, old_form ? kPreTH : kPre22TH);
     if (a.radius < 1) return fail(KDE_ERR_INVALID, "presmooth: radius %d", a.radius);

@@ -10,6 +10,7 @@
 // The accumulation order of the double sums is not fixed (atomics); results agree with the serial restatement
 // to ~1e-15 relative before the cast to float.
 #include "kde_internal.h"
+#include "kde_device_math.h"
 
 #include <type_traits>
 
@@ -238,15 +239,20 @@ __device__ __forceinline__ s_f2 s_add_clamp(s_f2 a, s_f2 b)
 
 constexpr int kSwBX = 32, kSwBY = 8;                  // threads; tile = 64 x 8 pixels
 __global__ __launch_bounds__(kSwBX* kSwBY) void mrf_sweep_kernel(int width, int height, const float* __restrict__ zin,
-                                                                const float* __restrict__ pfz, float* __restrict__ zout)
+                                                                const float* __restrict__ pfz, float* __restrict__ zout, int band)
 {
     constexpr int R = 2, WIN = 5, HALF = 2, TW = kSwBX * 2, TH = kSwBY, LW = TW + 2 * R, LH = TH + 2 * R;
     __shared__ __attribute__((aligned(8))) float sz[LH * LW];
-    {   // blockIdx.z = frame of a batch
-        const size_t fpx = (size_t)blockIdx.z * width * height;
+    // 1-D grid of frames x tiles walked in XCD bands (kde_device_math.h): vertically adjacent tiles share 4 of their 12
+    // staged rows, and a sweep reads what the previous sweep's neighbours wrote -- within one XCD's L2 instead of across the fabric
+    const unsigned tiles_x = (unsigned)((width + TW - 1) / TW), tiles = tiles_x * (unsigned)((height + TH - 1) / TH);
+    const unsigned gid = band ? xcd_band_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned frame = gid / tiles, tile = gid - frame * tiles;
+    {
+        const size_t fpx = (size_t)frame * width * height;        // frame of a batch
         zin += fpx; pfz += fpx; zout += fpx;
     }
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int x0 = (int)(tile % tiles_x) * TW, y0 = (int)(tile / tiles_x) * TH;
     const int tx = threadIdx.x % kSwBX, ty = threadIdx.x / kSwBX;
     const int x = x0 + 2 * tx, y = y0 + ty;
     const bool own = x < width && y < height, has1 = own && x + 1 < width;
@@ -499,7 +505,8 @@ int launch_spdsr_plane_projection(int width, int height, int n, int nclusters, c
                        reinterpret_cast<const float4*>(nd), labels, pts, reinterpret_cast<const float2*>(nxy), plane_fitted,
                        zping, pfz);
     float *in = zping, *out = zpong;
-    dim3 grid(ceil_div(width, kSwBX * 2), ceil_div(height, kSwBY), n);
+    dim3 grid((unsigned)(ceil_div(width, kSwBX * 2) * ceil_div(height, kSwBY) * n));
+    static const int band = getenv("KDE_SWEEP_NO_BAND_WALK") == nullptr ? 1 : 0;      // A/B switch for tools/bench_spdsr.py
     // A/B switch for tools/bench_spdsr.py.  Measured on MI355X (r03): two sweeps per launch are bit-identical and SLOWER --
     // 0.978 vs 0.946 ms per 1080p frame, 0.383 vs 0.333 at 640x480 (150 workgroups there) -- so one sweep per launch stays.
     static const bool two_sweeps = getenv("KDE_SPDSR_TWO_SWEEPS") != nullptr;
@@ -512,7 +519,7 @@ int launch_spdsr_plane_projection(int width, int height, int n, int nclusters, c
         out = t;
     }
     for (; i < sweeps; i++) {
-        hipLaunchKernelGGL(mrf_sweep_kernel, grid, dim3(kSwBX * kSwBY), 0, s, width, height, in, pfz, out);
+        hipLaunchKernelGGL(mrf_sweep_kernel, grid, dim3(kSwBX * kSwBY), 0, s, width, height, in, pfz, out, band);
         float* t = in;
         in = out;
         out = t;
