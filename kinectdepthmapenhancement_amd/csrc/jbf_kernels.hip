@@ -707,6 +707,14 @@ long long presmooth_resident_blocks(int radius)
     }
 }
 
+// Whether the row-pair kernel walks its tiles in XCD bands.  The walk makes horizontally adjacent tiles (shared halo columns,
+// shared 128-byte lines) meet in one L2; measured inside the chain (tools/ab_k0_band.sh, profiles/r03_ab_k0_band.txt) it pays
+// while a launch's input fits the eight L2s and costs once each XCD streams its own distant band of a large batch.
+static int k0_band_walk(int width, int height, int n)
+{
+    return (long long)width * height * n * 3 <= (32ll << 20) ? 1 : 0;
+}
+
 int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
 {
     PreDev d;
@@ -718,8 +726,9 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
     d.n = a.n;
     constexpr int kPX = kPrePxPerThread;
     const bool old_form = a.radius > 2 || !k0_use_2x2();
-    static const bool band = getenv("KDE_K0_NO_BAND_WALK") == nullptr;      // A/B switch for tools/bench_k0.py
-    d.band_walk = band ? 1 : 0;
+    // KDE_K0_BAND_WALK=0/1 forces the walk (A/B: tools/ab_k0_band.sh, tools/bench_k0.py); default: see k0_band_walk()
+    static const int force = [] { const char* e = getenv("KDE_K0_BAND_WALK"); return e ? (e[0] != '0' ? 1 : 0) : -1; }();
+    d.band_walk = force >= 0 ? force : k0_band_walk(a.width, a.height, a.n);
     d.tiles_x = ceil_div(a.width, old_form ? kPreBX * kPX : kPre22TW);
     d.tiles_y = ceil_div(a.height, old_form ? kPreTH : kPre22TH);
     if (a.radius < 1) return fail(KDE_ERR_INVALID, "presmooth: radius %d", a.radius);
