@@ -255,14 +255,18 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
         const int xb = x0 + tx * kPrePX, y = y0 + ty;
         if (xb >= a.width || y >= a.height) continue;
 
-        // (b, g) accumulate as one packed pair (v_pk_fma_f32, same roundings as two fma); packing (r, weight sum)
-        // as well costs 8 more VGPRs for the {r, 1.0} operands and drops the kernel to 3 waves/SIMD
+        // (b, g) accumulate as one packed pair (v_pk_fma_f32, same roundings as two fma).  Measured and rejected (the kernel
+        // lives on its 7 resident waves, every extra live register spills): packing (r, weight sum) as well (8 more VGPRs for
+        // the {r, 1.0} operands), the weight sums of the two pixels as one pair (the table reads only land in adjacent
+        // registers through moves or spills: 0.142 ms), re-using the weight of the mutual tap of the pair (0.105-0.111 ms)
         uint32_t cc[kPrePX];
-        pre_f2 sbg[kPrePX], srw[kPrePX];
+        pre_f2 sbg[kPrePX];
+        float sr[kPrePX], sden[kPrePX];
 #pragma unroll
         for (int k = 0; k < kPrePX; k++) {
             cc[k] = sc[(ty + R) * LP + tx * kPrePX + R + k];
-            sbg[k] = srw[k] = pre_f2{0.0f, 0.0f};
+            sbg[k] = pre_f2{0.0f, 0.0f};
+            sr[k] = sden[k] = 0.0f;
         }
 #pragma unroll
         for (int dy = -R; dy <= R; dy++) {
@@ -296,34 +300,32 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
                     const int q = k + R + dx;
                     const uint32_t n1 = __builtin_amdgcn_sad_u8(v[q], cc[k], 0u);   // |db| + |dg| + |dr|
                     const float w = lut[space2 * 766 + n1];
-                    const pre_f2 ww = pre_f2{w, w};
-                    sbg[k] = __builtin_elementwise_fma(ww, fbg[q], sbg[k]);
-                    srw[k].x = __builtin_fmaf(w, fr[q], srw[k].x);
-                    srw[k].y += w;
+                    sbg[k] = __builtin_elementwise_fma(pre_f2{w, w}, fbg[q], sbg[k]);
+                    sr[k] = __builtin_fmaf(w, fr[q], sr[k]);
+                    sden[k] += w;
                 }
             }
         }
-        // The reference divides (IEEE) and rounds half-to-even to u8.  rcp + one Newton step is within 1 ulp
-        // (< 1.6e-5 below 256) of the quotient, which rounds to the same integer unless the quotient sits within
-        // that distance of k + 0.5; those (rare) lanes take the IEEE division, so the byte is the reference's.
+        // The reference divides (IEEE) and rounds half-to-even to u8.  num * rcp(den) is within 1.5 ulp (< 2.3e-5 below
+        // 256) of the exact quotient and the IEEE quotient within 0.5 ulp, so both round to the same integer unless the
+        // product sits within 1e-4 of k + 0.5; those (rare) lanes take the IEEE division, so the byte is the reference's.
         uint32_t px[kPrePX];
 #pragma unroll
         for (int k = 0; k < kPrePX; k++) {
-            const float den = srw[k].y;
+            const float den = sden[k];
             const float r = __builtin_amdgcn_rcpf(den);
-            float q[3] = {sbg[k].x, sbg[k].y, srw[k].x};
-            bool ambiguous = false;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float num = q[c];
-                const float q0 = num * r;
-                q[c] = __builtin_fmaf(__builtin_fmaf(-den, q0, num), r, q0);
-                ambiguous |= !(__builtin_fabsf(__builtin_amdgcn_fractf(q[c]) - 0.5f) > 1.0e-4f);   // NaN -> exact path
-            }
+            const pre_f2 qbg = sbg[k] * pre_f2{r, r};
+            float q[3] = {qbg.x, qbg.y, sr[k] * r};
+            const pre_f2 ebg = pre_f2{__builtin_amdgcn_fractf(q[0]), __builtin_amdgcn_fractf(q[1])} - pre_f2{0.5f, 0.5f};
+            const float er = __builtin_amdgcn_fractf(q[2]) - 0.5f;
+            // distance of the nearest channel to its rounding boundary (one v_min3_f32 with |.| modifiers); a weight sum
+            // that is not a positive normal number (NaN / infinite table entries from degenerate sigmas) -> exact path
+            const float emin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(ebg.x), __builtin_fabsf(ebg.y)), __builtin_fabsf(er));
+            const bool ambiguous = !(emin > 1.0e-4f) || !__builtin_amdgcn_class(den, 0x100);
             if (ambiguous) {
                 q[0] = sbg[k].x / den;
                 q[1] = sbg[k].y / den;
-                q[2] = srw[k].x / den;
+                q[2] = sr[k] / den;
             }
             // saturate_cast<uchar>: v_cvt_pk_u8_f32 rounds to nearest even, clamps to [0, 255] and packs the byte
             px[k] = cvt_pk_u8(q[2], 2u, cvt_pk_u8(q[1], 1u, cvt_pk_u8(q[0], 0u, 0u)));
