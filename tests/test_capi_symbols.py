@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -99,3 +100,37 @@ def test_product_does_not_reference_the_oracle():
     from kinectdepthmapenhancement_amd import _native
     out = subprocess.run(["ldd", _native.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_every_entry_point_rejects_null_arguments_without_a_gpu():
+    """Every int-returning entry point that takes a handle or an out-pointer first is called with all-zero arguments in a
+    child process: the answer must be KDE_ERR_INVALID (validation precedes any HIP call) — `*_destroy(NULL)` is a no-op like
+    `free(NULL)` — and the child must not crash."""
+    code = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, %r)
+from kinectdepthmapenhancement_amd import _native as N
+lib = N.lib()
+out = {}
+for name, (res, args) in N.SIGNATURES.items():
+    if res is not C.c_int or not args or args[0] not in (C.c_void_p, C.POINTER(C.c_void_p)):
+        continue
+    zeros = []
+    for a in args:
+        if a in (C.c_int, C.c_size_t):
+            zeros.append(0)
+        elif a is C.c_float:
+            zeros.append(0.0)
+        else:
+            zeros.append(None)
+    out[name] = getattr(lib, name)(*zeros)
+print(json.dumps(out))
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    import json
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(res) >= 60
+    from kinectdepthmapenhancement_amd import _native as N
+    bad = {k: v for k, v in res.items() if v != (N.KDE_OK if k.endswith("_destroy") else N.KDE_ERR_INVALID)}
+    assert not bad, bad
