@@ -711,7 +711,10 @@ long long presmooth_resident_blocks(int radius)
 
 // Whether the row-pair kernel walks its tiles in XCD bands.  The walk makes horizontally adjacent tiles (shared halo columns,
 // shared 128-byte lines) meet in one L2; measured inside the chain (tools/ab_k0_band.sh, profiles/r03_ab_k0_band.txt) it pays
-// while a launch's input fits the eight L2s and costs once each XCD streams its own distant band of a large batch.
+// while a launch's input fits the eight L2s (one 1080p frame 18.2 -> 15.5 us, one 640x480 frame 9.1 -> 8.2 us) and costs on a
+// large batch (64 x 640x480 inside the headline step: 0.103 -> 0.110 ms although the fetched bytes halve; groups of 2 or 4
+// adjacent tiles per XCD inside one moving window of the batch: 0.109 / 0.111 ms) -- neighbouring tiles that stage the same
+// lines at the same time queue on one L2 channel instead of being served by eight.
 static int k0_band_walk(int width, int height, int n)
 {
     return (long long)width * height * n * 3 <= (32ll << 20) ? 1 : 0;

@@ -30,14 +30,38 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _code_only(text):
+    """the text without comments and with runs of whitespace collapsed: a comment edit does not make a profile stale"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":                       # string / character literal: copied verbatim
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c)
+            i += 1
+    return re.sub(r"\s+", " ", "".join(out)).strip()
+
+
 def source_hash():
-    """sha256 over the kernel sources: bench.py only quotes a profile taken on exactly this code"""
+    """sha256 over the kernel sources (code only, comments and layout ignored): bench.py only quotes a profile taken on
+    exactly this code"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "kinectdepthmapenhancement_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".cpp", ".h")):
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            h.update(_code_only(open(os.path.join(d, name), errors="replace").read()).encode())
     return h.hexdigest()[:16]
 
 
