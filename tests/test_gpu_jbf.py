@@ -40,6 +40,27 @@ def test_presmooth_k0_is_bit_exact(torch_cuda, F, oracle, frame, color_fixture):
         assert np.array_equal(host(out)[0], oracle.cv_bilateral(bgr, 5, 30.0, 30.0))
 
 
+def test_presmooth_tile_walks_agree(torch_cuda, F, oracle, frame):
+    """K0 walks its tiles in XCD bands while a launch's input fits the L2s (<= 32 MiB) and linearly beyond: a batch of 40
+    640x480 frames (36.9 MB, linear walk) must give, frame by frame, the bytes of the single-frame launches (band walk), and
+    frames 0 and 39 the oracle's; a ragged size puts partial tiles into both walks"""
+    for (w, h, n) in ((640, 480, 40), (637, 479, 40)):
+        base = np.stack([frame(20 + i, w, h)[0] for i in range(4)])
+        bgr = np.concatenate([np.roll(base, i, axis=2) for i in range(n // 4)])      # 40 distinct frames
+        assert bgr.nbytes > 32 << 20
+        big = F.JointBilateralFilter(w, h, max_batch=n)
+        one = F.JointBilateralFilter(w, h)
+        src = dev(torch_cuda, bgr)
+        out = torch_cuda.empty_like(src)
+        big.presmooth_batch(src, out)
+        single = torch_cuda.empty_like(src)
+        for i in range(n):
+            one.presmooth_batch(src[i:i + 1], single[i:i + 1])
+        assert torch_cuda.equal(out, single)
+        for i in (0, n - 1):
+            assert np.array_equal(host(out[i]), oracle.cv_bilateral(bgr[i], 5, 30.0, 30.0))
+
+
 @pytest.mark.parametrize("ksize,sc,ss", [(3, 10.0, 5.0), (7, 60.0, 2.0), (9, 25.0, 25.0), (0, 30.0, 1.7)])
 def test_presmooth_other_kernel_sizes(torch_cuda, F, oracle, frame, ksize, sc, ss):
     bgr = frame(6, 96, 64)[0]
