@@ -187,6 +187,8 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
 
     const int tid = threadIdx.x;
     for (int i = tid; i < LUT_N; i += NT) lut[i] = a.lut[i];
+    // weight of the centre tap (exp(0) = 1 unless the sigmas are degenerate): wave-uniform, kept in a scalar register
+    const float w_centre = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a.lut[0])));
 
     const int tiles_per_frame = a.tiles_x * a.tiles_y;
     const int total = tiles_per_frame * a.n;
@@ -258,7 +260,8 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
         // (b, g) accumulate as one packed pair (v_pk_fma_f32, same roundings as two fma).  Measured and rejected (the kernel
         // lives on its 7 resident waves, every extra live register spills): packing (r, weight sum) as well (8 more VGPRs for
         // the {r, 1.0} operands), the weight sums of the two pixels as one pair (the table reads only land in adjacent
-        // registers through moves or spills: 0.142 ms), re-using the weight of the mutual tap of the pair (0.105-0.111 ms)
+        // registers through moves or spills: 0.142 ms), re-using the weight of the mutual tap of the pair (0.105-0.111 ms),
+        // converting the six output bytes straight into a dword + a halfword (unaligned dword stores: 0.099 vs 0.098 ms)
         uint32_t cc[kPrePX];
         pre_f2 sbg[kPrePX];
         float sr[kPrePX], sden[kPrePX];
@@ -298,8 +301,13 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
 #pragma unroll
                 for (int k = 0; k < kPrePX; k++) {
                     const int q = k + R + dx;
-                    const uint32_t n1 = __builtin_amdgcn_sad_u8(v[q], cc[k], 0u);   // |db| + |dg| + |dr|
-                    const float w = lut[space2 * 766 + n1];
+                    float w;
+                    if (space2 == 0) {
+                        w = w_centre;                // the pixel itself: distance 0, n1 = 0 -- one table entry, no gather
+                    } else {
+                        const uint32_t n1 = __builtin_amdgcn_sad_u8(v[q], cc[k], 0u);   // |db| + |dg| + |dr|
+                        w = lut[space2 * 766 + n1];
+                    }
                     sbg[k] = __builtin_elementwise_fma(pre_f2{w, w}, fbg[q], sbg[k]);
                     sr[k] = __builtin_fmaf(w, fr[q], sr[k]);
                     sden[k] += w;
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
 }
 
 // --------------------------------------------------------------------------------------------
-// K0, 2 x 2 pixels per thread (r03; the default for radii 1..4).  The kernel above is bound by the VALU instructions
+// K0, 2 x 2 pixels per thread (r03; opt-in, KDE_K0_2X2=1: measured slower than the row-pair kernel above).  The kernel above is bound by the VALU instructions
 // it issues (184 per pixel at radius 2: 45 byte -> float conversions, 65 for the 13 taps, ~50 for the quotient /
 // rounding / packing), not by memory.  A thread that owns a 2 x 2 block loads each of its 2R + 2 window rows ONCE for
 // both output rows: 27 instead of 45 conversions per pixel; (r, weight) accumulate as one packed pair like (b, g):
