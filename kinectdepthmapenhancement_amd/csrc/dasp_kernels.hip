@@ -31,14 +31,22 @@ namespace {
 __global__ __launch_bounds__(256) void sample_clusters_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
                                                              const kde_float3* __restrict__ pts,
                                                              kde_superpixel* __restrict__ mean,
-                                                             kde_float3* __restrict__ centers)
+                                                             kde_float3* __restrict__ centers,
+                                                             kde_superpixel* __restrict__ mean2,
+                                                             kde_float3* __restrict__ centers2)
 {
+    // (mean2, centers2): a pipeline's second segmenter starts from the same sampled clusters -- written here instead of
+    // being copied device-to-device afterwards (two copy launches per frame); null for a single segmenter
     {
         const size_t fpx = (size_t)blockIdx.y * g.width * g.height, fk = (size_t)blockIdx.y * g.rows * g.cols;
         bgr += fpx * 3;
         pts += fpx;
         mean += fk;
         centers += fk;
+        if (mean2) {
+            mean2 += fk;
+            centers2 += fk;
+        }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane >> 4, tid = lane & 15;
@@ -108,8 +116,13 @@ __global__ __launch_bounds__(256) void sample_clusters_kernel(DaspGeom g, const 
         m.r = cs[0];
         m.g = cs[1];
         m.b = (uint8_t)(cs[0] + 2);   // sic, .cu:159
+        const kde_float3 c = pts[(size_t)ay * g.width + ax];
         mean[id] = m;
-        centers[id] = pts[(size_t)ay * g.width + ax];
+        centers[id] = c;
+        if (mean2) {
+            mean2[id] = m;
+            centers2[id] = c;
+        }
     }
 }
 
@@ -549,10 +562,10 @@ __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const
 }  // namespace
 
 int launch_dasp_sample(const DaspGeom& g, int n, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
-                       kde_float3* centers, hipStream_t s)
+                       kde_float3* centers, kde_superpixel* mean2, kde_float3* centers2, hipStream_t s)
 {
     hipLaunchKernelGGL(sample_clusters_kernel, dim3(ceil_div(g.rows * g.cols, 4), n), dim3(256), 0, s, g, bgr, pts, mean,
-                       centers);
+                       centers, mean2, centers2);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }

@@ -656,7 +656,7 @@ extern "C" int kde_dasp_segmentation(kde_dasp* h, const uint8_t* bgr_dev, const 
     hipStream_t s = as_stream(stream);
     // DepthAdaptiveSuperpixel.cu:570-586
     // init_LD (K5) is folded into the first calculateLD: its output is only ever read there
-    KDE_TRY(launch_dasp_sample(h->g, 1, bgr_dev, points_dev, h->mean.p, h->centers.p, s));
+    KDE_TRY(launch_dasp_sample(h->g, 1, bgr_dev, points_dev, h->mean.p, h->centers.p, nullptr, nullptr, s));
     for (int i = 0; i < iteration; i++) {
         KDE_TRY(launch_dasp_calc_ld(h->g, bgr_dev, points_dev, h->ld.p, h->mean.p, h->centers.p, h->labels.p,
                                     color_sigma, spatial_sigma, depth_sigma, i == 0, s));
@@ -889,20 +889,18 @@ struct Pipeline {
         // labels both maps in one pass.  Per-object results are exactly those of two separate Segmentation calls.
         hipStream_t s = as_stream(stream);
         const DaspGeom& g = SP->g;
-        const size_t k = (size_t)g.rows * g.cols * n;
         // The first assignment step reads the sampled clusters once for both segmenters and forms init_LD's
         // assignment in registers (calc_ld_kernel<.., FIRST>); DASP's own copy of the sampled clusters is only
         // needed as the starting point of its first analyzeClusters, i.e. when there is more than one iteration.
-        KDE_TRY(launch_dasp_sample(g, n, bgr, pts, SP->mean.p, SP->centers.p, s));
-        if (iters > 1) {
-            KDE_HIP_TRY(hipMemcpyAsync(DASP->mean.p, SP->mean.p, k * sizeof(kde_superpixel), hipMemcpyDeviceToDevice, s));
-            KDE_HIP_TRY(hipMemcpyAsync(DASP->centers.p, SP->centers.p, k * sizeof(kde_float3), hipMemcpyDeviceToDevice, s));
-        }
+        // (the sampling kernel writes that copy itself: no device-to-device copies between the launches)
+        KDE_TRY(launch_dasp_sample(g, n, bgr, pts, SP->mean.p, SP->centers.p, iters > 1 ? DASP->mean.p : nullptr,
+                                   iters > 1 ? DASP->centers.p : nullptr, s));
         const float sa[3] = {c1, s1, d1}, sb[3] = {c2, s2, d2};
         for (int i = 0; i < iters; i++) {
-            // the (distance, label) records are only read by a LATER assignment step: with one iteration they are not stored
+            // the (distance, label) records are only read by a LATER assignment step: the last step does not store them
+            // (the private segmenters of a pipeline expose labels only)
             KDE_TRY(launch_dasp_calc_ld_dual(g, n, bgr, pts, SP->ld.p, SP->mean.p, SP->centers.p, SP->labels.p, sa, DASP->ld.p,
-                                             DASP->mean.p, DASP->centers.p, DASP->labels.p, sb, i == 0, /*write_ld=*/iters > 1, s));
+                                             DASP->mean.p, DASP->centers.p, DASP->labels.p, sb, i == 0, /*write_ld=*/i < iters - 1, s));
             if (i == iters - 1) break;   // the trailing analyzeClusters is dead for the private segmenters
             // both objects got the same intrinsics in SetParametor, so one launch updates both cluster sets
             KDE_TRY(launch_dasp_analyze_dual(g, n, bgr, pts, SP->labels.p, SP->mean.p, SP->centers.p, DASP->labels.p,
@@ -1032,6 +1030,9 @@ extern "C" int kde_spdsr_set_parameters(kde_spdsr* h, int rows, int cols, const 
     KDE_TRY(h->cluster_nd.alloc(kb * 4));          // :52-53
     KDE_TRY(h->sums.alloc(kb * 4));
     KDE_TRY(h->cov.alloc(kb * 6));
+    // the moment tables are zero between calls: cluster_planes_kernel clears what it has consumed (no memsets per frame)
+    KDE_HIP_TRY(hipMemset(h->sums.p, 0, kb * 4 * sizeof(double)));
+    KDE_HIP_TRY(hipMemset(h->cov.p, 0, kb * 6 * sizeof(double)));
     KDE_HIP_TRY(hipMemset(h->cluster_nd.p, 0, kb * 4 * sizeof(float)));
     KDE_TRY(launch_spdsr_init_normalized(h->conv.cam, h->nxy.p, nullptr));
     KDE_HIP_TRY(hipStreamSynchronize(nullptr));

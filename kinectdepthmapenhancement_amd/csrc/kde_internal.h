@@ -184,7 +184,7 @@ struct DaspGeom {
 };
 // n = frames of a batch (per-frame colour / cloud / cluster tables / outputs, back to back); the single-frame forms take n = 1
 int launch_dasp_sample(const DaspGeom& g, int n, const uint8_t* bgr, const kde_float3* pts, kde_superpixel* mean,
-                       kde_float3* centers, hipStream_t s);
+                       kde_float3* centers, kde_superpixel* mean2, kde_float3* centers2, hipStream_t s);
 int launch_dasp_calc_ld(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, kde_label_distance* ld,
                         const kde_superpixel* mean, const kde_float3* centers, int32_t* labels, float color_sigma,
                         float spatial_sigma, float depth_sigma, bool first, hipStream_t s);

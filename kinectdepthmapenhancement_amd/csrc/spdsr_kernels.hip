@@ -141,8 +141,10 @@ __device__ void jacobi_eigen3(double A[3][3], double evals[3], double evecs[3][3
     }
 }
 
-__global__ __launch_bounds__(64) void cluster_planes_kernel(int nclusters, const double* __restrict__ sums,
-                                                           const double* __restrict__ cov, float4* __restrict__ nd)
+// The moment tables are accumulated with atomics into zeroed memory; this kernel is their only reader and clears the
+// entries it has consumed, so that the next call finds them zero again (instead of two memset launches per call).
+__global__ __launch_bounds__(64) void cluster_planes_kernel(int nclusters, double* __restrict__ sums,
+                                                           double* __restrict__ cov, float4* __restrict__ nd)
 {
     const int l = blockIdx.x * 64 + threadIdx.x;
     if (l >= nclusters) return;
@@ -170,6 +172,10 @@ __global__ __launch_bounds__(64) void cluster_planes_kernel(int nclusters, const
         v.x = v.y = v.z = 5.0f;
         nd[l] = v;
     }
+#pragma unroll
+    for (int k = 0; k < 4; k++) sums[l * 4 + k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) cov[l * 6 + k] = 0.0;
 }
 
 // ---- Projection_GPU ---------------------------------------------------------------------------------------
@@ -477,8 +483,7 @@ int launch_spdsr_cluster_planes(int width, int height, int n, int nclusters, con
                                 double* sums, double* cov, float* nd, hipStream_t s)
 {
     const int npix = width * height;
-    KDE_HIP_TRY(hipMemsetAsync(sums, 0, (size_t)n * nclusters * 4 * sizeof(double), s));
-    KDE_HIP_TRY(hipMemsetAsync(cov, 0, (size_t)n * nclusters * 6 * sizeof(double), s));
+    // sums / cov are zero on entry (cleared at creation and by cluster_planes_kernel after every use)
     const int use_lds = nclusters <= kMaxLdsClusters;
     const int blocks = ceil_div(npix, kThreads * 8);
     hipLaunchKernelGGL(cluster_moments_kernel<false>, dim3(blocks, n), dim3(kThreads), use_lds ? (size_t)nclusters * 4 * 8 : 0, s,

@@ -595,6 +595,45 @@ def test_fastdiv24_device_function_equals_integer_division(torch_cuda):
         assert np.array_equal(got, big // np.uint32(d)), (d, maxdiv)
 
 
+def test_spdsr_object_reuse_starts_from_clean_moment_tables(torch_cuda, F, oracle, synth):
+    """The per-cluster moment tables are accumulated with atomics into zeroed memory and cleared by the kernel that consumes
+    them (no memset launches per frame): a second, different frame — and a smaller batch after a larger one — on the SAME
+    object must give the planes a fresh object gives."""
+    w, h = 160, 120
+    t = torch_cuda
+    K = synth.intrinsics(w, h)
+    bgr, depth = synth.make_batch(760, 4, w, h)
+    pts = np.stack([pts_as_f32(oracle.p2r_depth(depth[f], K)) for f in range(4)])
+
+    def fresh(f):
+        sr = F.SPDepthSuperResolution(w, h)
+        sr.SetParametor(6, 8, K)
+        sr.Process(dev(t, depth[f]), dev(t, pts[f]), dev(t, bgr[f]))
+        return host(sr.getClusterND_Device()).copy(), host(sr.getOptimizedPoints_Device()).copy()
+
+    def same(a, b):
+        nd_a, o_a = a
+        nd_b, o_b = b
+        planes = (np.abs(nd_a[..., 0]) < 1.0) & (np.abs(nd_b[..., 0]) < 1.0)
+        assert np.array_equal(np.abs(nd_a[..., 0]) < 1.0, np.abs(nd_b[..., 0]) < 1.0)
+        assert np.allclose(nd_a[planes], nd_b[planes], rtol=2e-5, atol=2e-6)
+        fin = np.isfinite(o_a).all(-1) & np.isfinite(o_b).all(-1)
+        assert np.array_equal(np.isfinite(o_a), np.isfinite(o_b)) and np.allclose(o_a[fin], o_b[fin], rtol=1e-4, atol=1e-2)
+
+    one = F.SPDepthSuperResolution(w, h)
+    one.SetParametor(6, 8, K)
+    for f in (0, 1, 0):                                  # A, B, A again on one object
+        one.Process(dev(t, depth[f]), dev(t, pts[f]), dev(t, bgr[f]))
+        same((host(one.getClusterND_Device()), host(one.getOptimizedPoints_Device())), fresh(f))
+    many = F.SPDepthSuperResolution(w, h, max_batch=4)
+    many.SetParametor(6, 8, K)
+    many.process_batch(dev(t, depth), dev(t, pts), dev(t, bgr))                    # 4 frames ...
+    many.process_batch(dev(t, depth[2:4]), dev(t, pts[2:4]), dev(t, bgr[2:4]))      # ... then 2 others in slots 0, 1
+    nd, opt = host(many.getClusterND_Device()), host(many.getOptimizedPoints_Device())
+    for slot, f in ((0, 2), (1, 3)):
+        same((nd[slot], opt[slot]), fresh(f))
+
+
 def test_spdsr_two_sweeps_per_launch_equal_single_sweeps_bitwise(torch_cuda, tmp_path):
     """The measured-and-rejected two-sweeps-per-launch form of Projection_GPU's 20 mrf_optimization sweeps
     (mrf_sweep2_kernel, KDE_SPDSR_TWO_SWEEPS=1, read once per process): per pixel the arithmetic is the single-sweep
