@@ -152,6 +152,7 @@ struct PreDev {
     int width, height, n;
     int tiles_x, tiles_y;
     int band_walk;          // tiles are walked in XCD bands (row-pair kernel)
+    FastDiv24 div_tpf, div_tx;      // tile index -> (frame, tile of the frame) -> (tile row, tile column) by multiplication
 };
 
 constexpr int kPreBX = 16, kPreBY = 16;
@@ -197,65 +198,86 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
     // Staging slots of this thread (tile-independent LDS coordinates), and a register prefetch of the NEXT tile:
     // its global loads are issued before the current tile is computed and are only waited for when they are
     // written to LDS, so their latency hides behind the tap loop.
-    constexpr int NSLOT = (LW * LH + NT - 1) / NT;
-    int slot_x[NSLOT], slot_y[NSLOT];
-#pragma unroll
-    for (int k = 0; k < NSLOT; k++) {
-        const int i = tid + k * NT;
-        slot_y[k] = i / LW;
-        slot_x[k] = i - slot_y[k] * LW;
-    }
+    // A thread stages column sx of rows sy0, sy0 + RPP, sy0 + 2 RPP, ... of the tile + halo (RPP rows per pass, LW threads per
+    // row; NT - RPP * LW threads idle): slot k then differs from slot 0 by a wave-uniform amount -- k * RPP rows -- in the
+    // image (folded into the scalar base address) and in LDS (an immediate offset), so a thread keeps ONE byte offset and ONE
+    // LDS address for all its slots, and interior tiles stage with no per-slot address arithmetic at all.
+    constexpr int RPP = NT / LW;
+    constexpr int NSLOT = (LH + RPP - 1) / RPP;
+    const int sy0 = tid / LW, sx = tid - sy0 * LW;
+    const bool stager = sy0 < RPP;
+    const uint32_t lds0 = (uint32_t)(sy0 * LP + sx);
+    const uint32_t rel0 = ((uint32_t)sy0 * (uint32_t)a.width + (uint32_t)sx) * 3u;
+    const uint32_t out_rel = ((uint32_t)ty * (uint32_t)a.width + (uint32_t)(tx * kPrePX)) * 3u;
     const size_t last_pix = (size_t)a.n * a.width * a.height - 1;     // its 4-byte read would leave the buffer
     // Tile walk: linear index L (this workgroup's k-th tile is blockIdx.x + k * gridDim.x) -> tile xcd_band_id(L, total), so
     // that each XCD works through a contiguous band of the tile list and horizontally adjacent tiles -- which share their
     // halo columns and, being only 96 bytes wide, their 128-byte lines -- meet in ONE L2 (KDE_K0_BAND_WALK, see launch_presmooth)
     auto tile_of = [&](int L) { return a.band_walk ? (int)xcd_band_id((unsigned)L, (unsigned)total) : L; };
-    auto fetch = [&](int L, uint32_t* pre) {
-        const int t = tile_of(L);
-        const int frame_i = t / tiles_per_frame;
-        const int tile = t - frame_i * tiles_per_frame;
-        const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+    // (frame, tile row, tile column) of linear tile index L: computed ONCE per tile (when it is prefetched) and carried to
+    // the iteration that computes it; the two divisions are multiplications (fastdiv24, exact for < 2^24 tiles)
+    struct TileAt { int frame_i, tyi, txi; };
+    auto tile_at = [&](int L) {
+        const uint32_t t = (uint32_t)tile_of(L);
+        const uint32_t f = fastdiv24(t, a.div_tpf);
+        const uint32_t tile = t - f * (uint32_t)tiles_per_frame;
+        const uint32_t ty_ = fastdiv24(tile, a.div_tx);
+        return TileAt{(int)f, (int)ty_, (int)(tile - ty_ * (uint32_t)a.tiles_x)};
+    };
+    auto fetch = [&](const TileAt& at, uint32_t* pre) {
+        const int frame_i = at.frame_i, tyi = at.tyi, txi = at.txi;
         const size_t frame = (size_t)frame_i * a.width * a.height;
-        // a tile whose halo stays inside the image needs no border reflection (workgroup-uniform)
+        // a tile whose halo stays inside the image needs no border reflection (workgroup-uniform); the one tile whose halo
+        // ends on the last pixel of the whole batch takes the general path (the 4-byte read of that pixel is split there)
+        const bool ends_batch = frame_i == a.n - 1 && txi * kPreTW + kPreTW + R == a.width && tyi * kPreTH + kPreTH + R == a.height;
         const bool inner = txi * kPreTW - R >= 0 && txi * kPreTW + kPreTW + R <= a.width && tyi * kPreTH - R >= 0 &&
-                           tyi * kPreTH + kPreTH + R <= a.height;
+                           tyi * kPreTH + kPreTH + R <= a.height && !ends_batch;
+        if (inner) {
+            const uint8_t* base = a.src + (frame + (size_t)(tyi * kPreTH - R) * a.width + (size_t)(txi * kPreTW - R)) * 3;
+#pragma unroll
+            for (int k = 0; k < NSLOT; k++) {
+                if (stager && sy0 + k * RPP < LH)        // one (unaligned) global_load_dword: scalar base + 32-bit offset
+                    __builtin_memcpy(&pre[k], base + (size_t)(k * RPP) * a.width * 3 + rel0, 4);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NSLOT; k++) {
-            if (tid + k * NT < LW * LH) {
-                const int ux = txi * kPreTW + slot_x[k] - R, uy = tyi * kPreTH + slot_y[k] - R;
-                const int gx = inner ? ux : reflect101(ux, a.width);
-                const int gy = inner ? uy : reflect101(uy, a.height);
+            if (stager && sy0 + k * RPP < LH) {
+                const int gx = reflect101(txi * kPreTW + sx - R, a.width);
+                const int gy = reflect101(tyi * kPreTH + sy0 + k * RPP - R, a.height);
                 const size_t pix = frame + (size_t)gy * a.width + gx;
-                if (pix < last_pix) {
-                    uint32_t v;
-                    __builtin_memcpy(&v, a.src + pix * 3, 4);          // one (unaligned) global_load_dword
-                    pre[k] = v & 0x00ffffffu;
-                } else {
-                    pre[k] = load_bgrx(a.src, pix);
-                }
+                if (pix < last_pix) __builtin_memcpy(&pre[k], a.src + pix * 3, 4);
+                else pre[k] = load_bgrx(a.src, pix);
             }
         }
     };
 
     uint32_t pre[NSLOT];
-    if ((int)blockIdx.x < total) fetch(blockIdx.x, pre);
+    TileAt cur{0, 0, 0};
+    if ((int)blockIdx.x < total) {
+        cur = tile_at(blockIdx.x);
+        fetch(cur, pre);
+    }
     for (int L = blockIdx.x; L < total; L += gridDim.x) {
-        const int t = tile_of(L);
-        const int frame_i = t / tiles_per_frame;
-        const int tile = t - frame_i * tiles_per_frame;
-        const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
-        const int x0 = txi * kPreTW, y0 = tyi * kPreTH;
+        const int frame_i = cur.frame_i;
+        const int x0 = cur.txi * kPreTW, y0 = cur.tyi * kPreTH;
         const size_t frame = (size_t)frame_i * a.width * a.height;
 
         __syncthreads();   // previous tile fully consumed (also orders the LUT staging before first use)
 #pragma unroll
         for (int k = 0; k < NSLOT; k++)
-            if (tid + k * NT < LW * LH) sc[slot_y[k] * LP + slot_x[k]] = pre[k];
+            if (stager && sy0 + k * RPP < LH) sc[lds0 + k * RPP * LP] = pre[k] & 0x00ffffffu;     // the 4th byte belongs to the next pixel
         __syncthreads();
-        if (L + (int)gridDim.x < total) fetch(L + gridDim.x, pre);
+        if (L + (int)gridDim.x < total) {
+            cur = tile_at(L + gridDim.x);
+            fetch(cur, pre);
+        }
 
+        // a tile that lies fully inside the image (workgroup-uniform) needs no per-pixel bounds tests
+        const bool full = x0 + kPreTW <= a.width && y0 + kPreTH <= a.height;
         const int xb = x0 + tx * kPrePX, y = y0 + ty;
-        if (xb >= a.width || y >= a.height) continue;
+        if (!full && (xb >= a.width || y >= a.height)) continue;
 
         // (b, g) accumulate as one packed pair (v_pk_fma_f32, same roundings as two fma).  Measured and rejected (the kernel
         // lives on its 7 resident waves, every extra live register spills): packing (r, weight sum) as well (8 more VGPRs for
@@ -338,17 +360,20 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
             // saturate_cast<uchar>: v_cvt_pk_u8_f32 rounds to nearest even, clamps to [0, 255] and packs the byte
             px[k] = cvt_pk_u8(q[2], 2u, cvt_pk_u8(q[1], 1u, cvt_pk_u8(q[0], 0u, 0u)));
         }
-        uint8_t* o = a.dst + (frame + (size_t)y * a.width + xb) * 3;
+        // wave-uniform tile origin + this thread's 32-bit offset inside the tile (out_rel, formed once per kernel)
+        uint8_t* o = a.dst + (frame + (size_t)y0 * a.width + x0) * 3 + out_rel;
         if (PX == 4 && (a.width & 3) == 0 && xb + 3 < a.width && (reinterpret_cast<uintptr_t>(a.dst) & 3u) == 0) {
             uint32_t* ow = reinterpret_cast<uint32_t*>(o);                  // 4 pixels = 12 bytes = 3 dwords
             ow[0] = px[0] | (px[1] << 24);
             ow[1] = (px[1] >> 8) | (px[2] << 16);
             ow[2] = (px[2] >> 16) | (px[3 % PX] << 8);
-        } else if (PX == 2 && xb + 1 < a.width && (reinterpret_cast<uintptr_t>(o) & 1u) == 0) {
-            uint16_t* oh = reinterpret_cast<uint16_t*>(o);                  // 2 pixels = 6 bytes = 3 halfwords
-            oh[0] = (uint16_t)(px[0] & 0xffffu);
-            oh[1] = (uint16_t)((px[0] >> 16) | ((px[1] & 0xffu) << 8));
-            oh[2] = (uint16_t)(px[1] >> 8);
+        } else if (PX == 2 && (full || xb + 1 < a.width)) {
+            // 2 pixels = 6 bytes = 3 halfword stores (global stores take any alignment: odd widths / odd base addresses)
+            const uint16_t h0 = (uint16_t)(px[0] & 0xffffu), h1 = (uint16_t)((px[0] >> 16) | ((px[1] & 0xffu) << 8)),
+                           h2 = (uint16_t)(px[1] >> 8);
+            __builtin_memcpy(o, &h0, 2);
+            __builtin_memcpy(o + 2, &h1, 2);
+            __builtin_memcpy(o + 4, &h2, 2);
         } else {
 #pragma unroll
             for (int k = 0; k < kPrePX; k++)
@@ -754,6 +779,8 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
     }
     const long long total = (long long)d.tiles_x * d.tiles_y * a.n;
     if (total > 0x7fffffffLL) return fail(KDE_ERR_INVALID, "presmooth: batch too large for one launch");
+    d.div_tpf = make_fastdiv24((uint32_t)(d.tiles_x * d.tiles_y), (uint64_t)total);
+    d.div_tx = make_fastdiv24((uint32_t)d.tiles_x, (uint64_t)d.tiles_x * d.tiles_y);
     const long long cap = a.grid_cap > 0 ? a.grid_cap : 256;
     const unsigned grid = (unsigned)(total < cap ? total : cap);
     if (old_form) {
