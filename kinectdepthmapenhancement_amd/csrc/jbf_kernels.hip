@@ -710,7 +710,10 @@ int launch_jbf(const JbfLaunch& a, hipStream_t s)
 // persistent-grid size of the tuned K0 kernels on the CURRENT device: every CU filled to the occupancy the variant
 // reaches (LDS table + VGPRs), no second wave.  Asked once per handle (kde_jbf_create) and kept there -- a handle
 // belongs to the device it was created on -- so nothing is cached across devices or threads here.
-constexpr int kPrePxPerThread = 2;                          // pixels per thread (A/B: 4)
+#ifndef KDE_K0_PX
+#define KDE_K0_PX 2
+#endif
+constexpr int kPrePxPerThread = KDE_K0_PX;                  // pixels per thread (A/B: -DKDE_K0_PX=4, tools/ab_k0_build.sh)
 
 // A/B switch (tools/bench_k0.py): KDE_K0_2X2=1 selects the 2 x 2-pixels-per-thread form for radii 1 and 2.  It issues 25 %
 // fewer instructions but needs 146 VGPRs (3 waves per SIMD instead of 6) and measured 0.146 vs 0.115 ms on 64 x VGA.
