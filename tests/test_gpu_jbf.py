@@ -32,7 +32,9 @@ def params(F, w=5, ss=70.0, cs=50.0, ds=20.0, pre=1, pk=5, pc=30.0, ps=30.0):
 
 
 def test_presmooth_k0_is_bit_exact(torch_cuda, F, oracle, frame, color_fixture):
-    for bgr in (color_fixture, frame(2)[0], frame(4, 70, 50)[0], frame(4, 33, 9)[0]):
+    # (66 x 34 and 98 x 50: the halo of the last interior tile ends exactly on the last pixel of the buffer, whose 4-byte
+    #  read the staging code must split; 33 x 9: a single partial tile)
+    for bgr in (color_fixture, frame(2)[0], frame(4, 70, 50)[0], frame(4, 33, 9)[0], frame(5, 66, 34)[0], frame(6, 98, 50)[0]):
         h, w, _ = bgr.shape
         jbf = F.JointBilateralFilter(w, h)
         out = torch_cuda.empty((1, h, w, 3), dtype=torch_cuda.uint8, device="cuda")
