@@ -142,3 +142,30 @@ def test_k1_stage_sub_unit_weights_that_survive_by_double_rounding(oracle):
     zero[4, 5] = 0.0
     st2 = oracle.jbf_stage(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds), avg_in=avg)
     assert not oracle.stage_check(zero, st2)["bad"].any()
+
+
+def test_k1_stage_open_decisions_on_both_sides_of_the_mean(oracle):
+    """tools/stress_parity.py seed 501 case 38542 (crop: tests/golden/k1_mixed_open_decisions.npz; window 31, sigma_s 0.5, colour
+    term off, sigma_d 70).  The spatial table underflows beyond r^2 = 52, so far taps enter with weight 1 (Q1) and the average
+    (2489 mm) sits between a near surface (1435 mm) and a far one (3500 mm), 1009.4 mm = the depth-factor underflow distance
+    from BOTH: one tap at 1479.95 mm lies 5e-9 (relative, in x) beyond the underflow point and one at 3498.83 mm 8e-5 beyond.
+    The float32 code skips the first (full weight) and keeps the second; taking the open decisions of all taps the same way
+    brackets [2133.30, 2135.16] and misses its value 2136.88 — the extremes are the MIXED decisions."""
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "k1_mixed_open_decisions.npz"))
+    win, ss, cs, ds = z["params"]
+    y, x = (int(v) for v in z["pixel"])
+    out = oracle.jbf_kernel(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds))
+    st = oracle.jbf_stage(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds))
+    # (only the crop's centre pixel has its whole window inside the crop; there the HIP kernel had returned the same bits)
+    assert abs(float(out[y, x]) - 2136.8796) < 1e-3 and out[y, x] == z["got"][y, x]
+    assert st.flags[y, x] & oracle.Stage.BAND
+    assert st.lo[y, x] < 2133.4 and st.hi[y, x] > 2136.87 and st.hi[y, x] - st.lo[y, x] < 6.0
+    assert 2135.0 < st.fin64[y, x] < 2135.3               # the arithmetic's own decisions at this average: one tap differs
+    assert not oracle.stage_check(out, st)["bad"].any()
+    # the bracket is not a blank cheque: a value one more tap away on either side is still rejected
+    for delta in (+2.0, -7.5):
+        bad = out.copy()
+        bad[y, x] += np.float32(delta)
+        assert oracle.stage_check(bad, st)["bad"][y, x]
