@@ -651,7 +651,13 @@ void okde_jbf_stage(int width, int height, const float* depth, const uint8_t* gu
                         }
                     }
                 }
-                if (grid1 || open1 || (dens[1] > 0.0 && dens[1] < 0x1p-110)) {
+                /* pass 2's own sub-threshold taps: an exact weight S cf df below 2^-150 that a float32 evaluation can still hold
+                 * (exp(-x) rounds up to a whole unit, and so does its product with S: stress seed 503, case 19859 -- a hole
+                 * between a 1000 mm and a 3000 mm surface at sigma_d = 70, every weight 0.3 .. 0.5 units, result round(d) of
+                 * the survivors) while no heavier tap decides the sum */
+                int sub2 = 0;
+                for (int k = 0; k < t.n; k++) sub2 |= w2[k] > kTinyW && w2[k] <= kUnder;
+                if (grid1 || open1 || (dens[1] > 0.0 && dens[1] < 0x1p-110) || (sub2 && !(dens[1] >= 0x1p-110))) {
                     /* sums on the float32 denormal grid: see grid_extremes() */
                     flag |= OKDE_STAGE_BAND | OKDE_STAGE_GRID;
                     double glo, ghi;
@@ -1628,7 +1634,9 @@ void okde_ers_stage(int width, int height, const float* rd, const uint8_t* bgr, 
                         }
                     }
                 }
-                if ((grid1 || open1 || (dens[1] > 0.0 && dens[1] < 0x1p-110)) && fin == fin) {
+                int sub3 = 0;        /* as sub2 in okde_jbf_stage */
+                for (int k = 0; k < t.n; k++) sub3 |= w3[k] > kTinyW && w3[k] <= kUnder;
+                if ((grid1 || open1 || (dens[1] > 0.0 && dens[1] < 0x1p-110) || (sub3 && !(dens[1] >= 0x1p-110))) && fin == fin) {
                     /* sums on the float32 denormal grid: see grid_extremes() */
                     flag |= OKDE_STAGE_BAND | OKDE_STAGE_GRID;
                     double glo, ghi;

@@ -169,3 +169,30 @@ def test_k1_stage_open_decisions_on_both_sides_of_the_mean(oracle):
         bad = out.copy()
         bad[y, x] += np.float32(delta)
         assert oracle.stage_check(bad, st)["bad"][y, x]
+
+
+def test_k1_stage_pass2_weights_below_the_underflow_point_that_survive(oracle):
+    """tools/stress_parity.py seed 503 case 19859 (crop: tests/golden/k1_pass2_subunit_survivors.npz; window 5, sigma_s 0.5, colour
+    term off, sigma_d 70): a hole whose left neighbours lie at 3000 mm and right neighbours at 1000 mm.  Its average (2000.2)
+    is 1000 mm from every tap, x = 102 — every pass-2 weight S exp(-x) is 0.3 .. 0.5 denormal units, below the float32
+    underflow point, yet exp(-x) alone is 4 units and its product with S = 0.135 rounds UP to one unit: the float32 code
+    returns round(d) of the survivors (1000.0) where the exact weights give "no weight".  Such pixels are GRID in pass 2 as
+    well: 0 and every value the surviving taps can produce are admissible."""
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "k1_pass2_subunit_survivors.npz"))
+    win, ss, cs, ds = z["params"]
+    y, x = (int(v) for v in z["pixel"])
+    out = oracle.jbf_kernel(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds))
+    st = oracle.jbf_stage(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds))
+    assert out[y, x] == 1000.0 and out[y, x] == z["got"][y, x] and z["depth"][y, x] == 0.0
+    f = st.flags[y, x]
+    assert f & oracle.Stage.GRID and f & oracle.Stage.ZERO_OK and not f & (oracle.Stage.NOWEIGHT | oracle.Stage.MISMATCH)
+    assert st.fin64[y, x] == 0.0 and st.lo[y, x] <= 1000.0 <= st.hi[y, x]
+    assert not oracle.stage_check(out, st)["bad"][y, x]
+    zero = out.copy()
+    zero[y, x] = 0.0                       # an implementation that flushes the sub-unit weights: admissible as well
+    assert not oracle.stage_check(zero, st)["bad"][y, x]
+    far = out.copy()
+    far[y, x] = 5000.0                     # ... but not a value no tap of the window can produce
+    assert oracle.stage_check(far, st)["bad"][y, x]
