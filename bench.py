@@ -5,7 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one JointBilateralFilter::Process (K0 colour pre-smoothing + K1 joint bilateral filter)
-over one batch of synthetic RGB-D frames that is already resident in HBM.  At N=1 the workload is
+over one batch of synthetic RGB-D frames that is already resident in HBM, made through the boundary entry
+point a caller uses: ONE kde_jbf_process_batch call per step (the drop-in of JointBilateralFilter::Process,
+JointBilateralFilter.cu:283-290), two HIP events around each step.  The K0 / K1 split that `roofline` reads
+is measured in a second, equally long leg right after (kde_jbf_presmooth_batch + kde_jbf_filter_batch, the
+two launches the boundary call makes, three events per step).  At N=1 the workload is
 BASELINE config 2's filter on a batch of 640x480 frames (64 frames per GPU: at N=8 that is config 4,
 512 frames sharded 8 ways; weak scaling, no data-path collective — frames are independent units;
 the only exchange is one broadcast of the parameter block from rank 0).
@@ -59,6 +63,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-gpu", type=int, default=64)
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="strong scaling: a FIXED batch (BASELINE config 4 as written: 512) cut into ceil(T/N) frames per GPU; "
+                         "0 = weak scaling with --frames-per-gpu frames on every GPU (the default)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--window", type=int, default=11, help="BASELINE 'radius=5' -> 2*5+1")
@@ -70,48 +77,69 @@ def parse():
                     help="untimed load before the W warm-up steps so that the GPU has left its idle clock level (0 = none)")
     ap.add_argument("--distinct-frames", type=int, default=8, help="distinct synthetic frames, tiled to the batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the 1080p / reference-constant side measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 1080p / chain / reference-constant side measurements")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_bench.json"))
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed output")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend of the N > 1 path (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
                     help="every rank uses cuda:0 (rehearsal of the N > 1 path on a one-GPU box; needs --backend gloo)")
+    ap.add_argument("--force-rccl-failure", action="store_true",
+                    help="make the RCCL bring-up raise on every rank: exercises SURVEY 8(e)'s in-process fallback (gloo, [REPLICAS ONLY])")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("KDE_BENCH_LAUNCH_TIMEOUT", "1500")),
+                    help="N > 1 without a launcher: seconds after which the parent ends every rank it started (exact PIDs)")
     ap.add_argument("--first-frame", type=int, default=0, help="global index of the first frame (N = 1 runs of one shard of a larger batch)")
     ap.add_argument("--no-idle-leg", action="store_true", help="skip the from-idle measurement that precedes the headline (profiling runs)")
     ap.add_argument("--dump-frames", default="",
                     help="write this rank's input frames (all colour frames, then all depth frames, raw) for examples/shard_replay --frames-file")
     ap.add_argument("--dry-run", action="store_true",
-                    help="everything but the GPU work: launch, process group, parameter broadcast, partition, reductions (CPU test of the N > 1 path)")
+                    help="everything but the GPU work: launch, process groups, fallback, parameter broadcast, partition, the reductions of "
+                         "every leg with stand-in timings (CPU test of the N > 1 path)")
     return ap.parse_args()
 
 
 def launch_ranks(args):
     """`python bench.py --gpus N` with N > 1 and no launcher: spawn the N ranks ourselves -- one process per GPU, started
     BEFORE anything touches a GPU (this parent never imports torch.cuda), with the environment torch.distributed.run
-    would give them -- relay rank 0's single JSON line and return the worst exit code."""
+    would give them -- relay rank 0's single JSON line and return the worst exit code.
+
+    HSA_ENABLE_IPC_MODE_LEGACY=0 (kept if the caller set it, as this image and the GPU pool do): the pool's host driver only
+    supports dmabuf IPC; with the legacy mode RCCL's intra-node P2P set-up -- which exports its buffers to the other ranks
+    through HIP IPC handles -- fails in hipIpcGetMemHandle with "invalid argument".  The data path never uses IPC (frames
+    are not exchanged); only RCCL's own bring-up for the parameter broadcast does."""
+    import threading
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+        port = sk.getsockname()[1]      # released here and re-bound by rank 0's store: a stolen port fails the launch loudly (rc != 0)
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    # a rank that dies leaves the others waiting in a collective: give them a grace period, then end them (exact PIDs)
-    failed_at = None
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)    # drained while the ranks run:
+    reader.start()                                                                                    # a full pipe never blocks rank 0
+    # a rank that dies leaves the others waiting in a collective: give them a grace period, then end them (exact PIDs);
+    # ranks that all hang are ended at the overall deadline
+    deadline, failed_at, timed_out = time.time() + args.launch_timeout, None, False
     while any(q.poll() is None for q in procs):
+        now = time.time()
         if failed_at is None and any(q.poll() not in (None, 0) for q in procs):
-            failed_at = time.time()
-        if failed_at is not None and time.time() - failed_at > 30.0:
+            failed_at = now
+        if (failed_at is not None and now - failed_at > 30.0) or now > deadline:
+            timed_out = timed_out or now > deadline
             for q in procs:
                 if q.poll() is None:
                     q.kill()
         time.sleep(0.1)
-    out0 = procs[0].stdout.read().decode(errors="replace")
-    sys.stdout.write(out0)
+    reader.join(10.0)
+    sys.stdout.write(b"".join(chunks).decode(errors="replace"))
     sys.stdout.flush()
-    return max(abs(q.returncode) for q in procs)
+    rc = max(abs(q.returncode) for q in procs)
+    if timed_out:
+        print(f"bench.py: the ranks did not finish within --launch-timeout {args.launch_timeout:g} s and were ended", file=sys.stderr)
+        rc = rc or 124
+    return rc
 
 
 def pmc_lookup(path, window, variant_name=None):
@@ -220,17 +248,25 @@ def make_inputs(synth, torch, first_seed, n, w, h, distinct):
     return torch.from_numpy(bgr).cuda(), torch.from_numpy(depth).cuda()
 
 
-def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier, wakeup_ms=0.0):
-    """device wake-up, W untimed + exactly K timed steps; returns (wall seconds, K0 ms list, K1 ms list, wake-up steps)."""
+def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier, wakeup_ms=0.0, split=False):
+    """device wake-up, W untimed + exactly K timed steps.
+    split=False: a step is ONE boundary call, kde_jbf_process_batch (JointBilateralFilter::Process on the batch), with an event
+                 before and after it;
+    split=True : the two launches that call makes, issued separately (kde_jbf_presmooth_batch = K0, kde_jbf_filter_batch = K1)
+                 with an event between them: the per-kernel times `roofline` reads.
+    returns (wall seconds of the K steps, per-step ms list [K0 + K1 when split], K0 ms list | None, K1 ms list | None, wake-up steps)."""
     def step(evs=None):
         if evs:
             evs[0].record()
-        jbf.presmooth_batch(color, smooth)          # K0  (== what kde_jbf_process_batch launches)
+        if split:
+            jbf.presmooth_batch(color, smooth)          # K0
+            if evs:
+                evs[1].record()
+            jbf.filter_batch(depth, smooth, out)        # K1
+        else:
+            jbf.process_batch(depth, color, out)        # the drop-in of JointBilateralFilter::Process (.cu:283-290)
         if evs:
-            evs[1].record()
-        jbf.filter_batch(depth, smooth, out)        # K1
-        if evs:
-            evs[2].record()
+            evs[-1].record()
 
     barrier()                                       # also brings the RCCL communicator up before anything is timed
     # Device wake-up, before the W warm-up steps and outside every timed region: an idle MI355X sits at its lowest
@@ -245,7 +281,7 @@ def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier, wa
         woke += 10
     for _ in range(warmup):
         step()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3 if split else 2)] for _ in range(steps)]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -254,9 +290,10 @@ def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier, wa
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0                   # this rank's K steps, from the common start; MAX over ranks is taken
     barrier()                                       # by the caller (the collective's own latency is not part of a step)
-    k0 = [e[0].elapsed_time(e[1]) for e in evs]
-    k1 = [e[1].elapsed_time(e[2]) for e in evs]
-    return dt, k0, k1, woke
+    step_ms = [e[0].elapsed_time(e[-1]) for e in evs]
+    k0 = [e[0].elapsed_time(e[1]) for e in evs] if split else None
+    k1 = [e[1].elapsed_time(e[2]) for e in evs] if split else None
+    return dt, step_ms, k0, k1, woke
 
 
 def usable_cores():
@@ -297,6 +334,46 @@ def cpu_baseline(args, synth, seconds, threads=None):
                       f"through oracle/kde_oracle.c, " + (f"OpenMP over rows on {cores} threads" if cores > 1 else "one thread") + f", {el:.1f} s"}
 
 
+def device_identity(rank, local_rank, dry_run):
+    """what tells this rank's GPU apart from the others of the node (the line shows N distinct PCI addresses for N GPUs)"""
+    ident = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "pid": os.getpid()}
+    if not dry_run:
+        import ctypes
+        from kinectdepthmapenhancement_amd._native import check, lib
+        arch, bus, cus = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64), ctypes.c_int(0)
+        check(lib().kde_device_info(arch, 64, ctypes.byref(cus)))
+        check(lib().kde_device_pci_bus_id(bus, 64))
+        ident.update(arch=arch.value.decode(), pci_bus_id=bus.value.decode(), cu_count=cus.value)
+    return ident
+
+
+def reduce_shard_legs(per_rank, world):
+    """the side legs every rank ran on its own GPU, reduced like the headline: units of all ranks / MAX time over ranks."""
+    out = {}
+    for name in per_rank[0]:
+        legs = [r[name] for r in per_rank]
+        l0 = legs[0]
+        agg = {k: v for k, v in l0.items() if not isinstance(v, (float, list, dict)) or k in ("workload",)}
+        px_all = sum(l["px"] for l in legs)
+        if "dt_s" in l0:                    # K steps of the boundary call, started together
+            dt = max(l["dt_s"] for l in legs)
+            agg.update(process_mpix_s=px_all * l0["steps"] / dt / 1e6, ms_per_step=dt / l0["steps"] * 1e3,
+                       k0_avg_launch_ms=max(l["k0_ms"] for l in legs), k1_avg_launch_ms=max(l["k1_ms"] for l in legs),
+                       k1_mpix_s=px_all / (max(l["k1_ms"] for l in legs) * 1e-3) / 1e6,
+                       k1_ms_per_rank=[l["k1_ms"] for l in legs], px_per_gpu=l0["px"])
+        if "batched_ms" in l0:              # the batched chain
+            ms = max(l["batched_ms"] for l in legs)
+            agg.update(batched_ms=ms, batched_ms_per_frame=ms / l0["frames"], batched_mpix_s=px_all / ms / 1e3,
+                       batched_ms_per_rank=[l["batched_ms"] for l in legs],
+                       frames_bit_identical_to_single_calls=all(l.get("frames_bit_identical_to_single_calls", True) for l in legs))
+            for k in ("single_frame_calls_ms_per_frame", "single_frame_calls_mpix_s", "pipeline_only_batched_ms_per_frame"):
+                if k in l0:
+                    agg[k] = l0[k]          # rank 0's own figure (per GPU)
+        agg["n_gpus"] = world
+        out[name] = agg
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -306,7 +383,6 @@ def main():
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
     import torch
-    import torch.distributed as dist
     from kinectdepthmapenhancement_amd import sharding, synth
     from kinectdepthmapenhancement_amd._native import JbfParams
 
@@ -315,21 +391,17 @@ def main():
     local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} != --gpus {args.gpus}")
-    if args.share_device and args.backend == "nccl" and world > 1:
+    if args.share_device and args.backend == "nccl" and world > 1 and not args.force_rccl_failure:
         raise SystemExit("--share-device needs --backend gloo (RCCL wants one device per rank)")
-    use_dist = "RANK" in os.environ          # launched by torch.distributed.run or by launch_ranks (also for N = 1)
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        if args.backend == "nccl" and not args.dry_run:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
-        else:
-            dist.init_process_group("gloo")
-    barrier = dist.barrier if use_dist else (lambda: None)
+    # process groups: gloo for the rendezvous, RCCL on top of it if it comes up on every rank; else the in-process
+    # fallback of SURVEY 8(e) -- nothing is re-executed, the run is flagged [REPLICAS ONLY] (sharding.ShardComm)
+    comm = sharding.ShardComm(args.backend, local_rank, use_gpu=not args.dry_run, force_rccl_failure=args.force_rccl_failure)
+    barrier = comm.barrier
+    use_dist = comm.active
 
-    # ---- parameter block: rank 0 decides, everyone receives the same bytes --------------------------
+    # ---- parameter block: every rank forms it, rank 0's is broadcast, everyone compares ----------------
     if args.dry_run:
         p = JbfParams(args.window, args.spatial_sigma, args.color_sigma, args.depth_sigma, 1, 5, 30.0, 30.0)
         r = args.window // 2
@@ -340,30 +412,48 @@ def main():
         p = filters.JointBilateralFilter.default_params()
         p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma = args.window, args.spatial_sigma, args.color_sigma, args.depth_sigma
         host_table = lambda q: filters.JointBilateralFilter(8, 8, q).spatial_table()
-    blk = sharding.pack_params(p, table=host_table(p)) if rank == 0 else np.zeros(sharding.BLOCK_LEN)
-    blk = sharding.broadcast_params(blk)
+    mine = sharding.pack_params(p, table=host_table(p))
+    blk = comm.broadcast_params(mine)           # RCCL over xGMI when it is up, gloo otherwise
     p, _, _, _, table0 = sharding.unpack_params(blk)
-    replicas_only = False
-    if not np.array_equal(host_table(p), table0):
-        replicas_only = True        # would mean ranks disagree on the host-computed table: flag the run
+    disagree = int(comm.allreduce_sum([0.0 if np.array_equal(mine, blk) else 1.0])[0])
+    replicas_only = comm.replicas_only or disagree > 0      # flagged in the line: RCCL did not come up, or a rank's own block differs
+    ranks_seen = int(round(comm.allreduce_sum([1.0])[0]))
+    devices = comm.gather_objects(device_identity(rank, local_rank, args.dry_run))
+    rccl = {"wanted": comm.rccl_wanted, "ok": comm.backend_used == "nccl", "backend_used": comm.backend_used, "error": comm.rccl_error,
+            "ranks_whose_block_differs_from_rank0": disagree}
 
     # ---- this rank's shard of the global batch ------------------------------------------------------
-    total_frames = args.frames_per_gpu * world
+    strong = args.total_frames > 0
+    total_frames = args.total_frames if strong else args.frames_per_gpu * world
     first, count = sharding.partition(total_frames, world)[rank]
     first += args.first_frame
     W, H = args.width, args.height
+    sharding_txt = (f"contiguous frame blocks x{world}, params broadcast from rank 0 ({comm.backend_used}"
+                    + (", all ranks on cuda:0" if args.share_device else "") + ")"
+                    + (f" [REPLICAS ONLY] ({comm.rccl_error or 'parameter blocks differ'})" if replicas_only else ""))
     if args.dry_run:
         barrier()
-        dt = sharding.allreduce_max(1e-3 * (rank + 1))
-        checksum = sharding.allreduce_sum([float(first), float(count)])
+        while os.environ.get("KDE_BENCH_TEST_HANG"):        # tests/test_bench_launch.py: the parent's deadline must end us
+            time.sleep(1.0)
+        dt = comm.allreduce_max(1e-3 * (rank + 1))
+        checksum = comm.allreduce_sum([float(first), float(count)])
+        # the side legs' reductions on stand-in timings (rank r is r + 1 times slower than rank 0)
+        fake = {"fhd_w19_config3": {"workload": "stand-in", "px": 32 * 1920 * 1080, "steps": 3, "dt_s": 0.03 * (rank + 1),
+                                    "k0_ms": 0.5 * (rank + 1), "k1_ms": 10.0 * (rank + 1)},
+                "vga_chain_batch64": {"frames": 64, "px": 64 * 640 * 480, "batched_ms": 1.7 * (rank + 1)}}
+        legs = reduce_shard_legs(comm.gather_objects(fake), world)
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "dry_run": True, "max_dt_over_ranks": dt, "replicas_only": replicas_only,
+                              "scaling": "strong" if strong else "weak", "ranks_seen": ranks_seen, "devices": devices, "rccl": rccl,
                               "checksum": {"sum_first_frames": checksum[0], "frames": int(checksum[1])},
-                              "config": {"window": p.window_size, "frames_per_gpu": count}}), file=real_stdout, flush=True)
-        if use_dist:
-            dist.destroy_process_group()
+                              "roofline": {"fhd_w19": legs["fhd_w19_config3"]}, "also": {"vga_chain_batch64": legs["vga_chain_batch64"]},
+                              "config": {"window": p.window_size, "frames_per_gpu": count, "sharding": sharding_txt}}),
+                  file=real_stdout, flush=True)
+        comm.close()
         return
+    if count < 1:
+        raise SystemExit(f"rank {rank}: empty shard ({total_frames} frames over {world} GPUs)")
     color, depth = make_inputs(synth, torch, first, count, W, H, args.distinct_frames)
     if args.dump_frames and rank == 0:
         with open(args.dump_frames, "wb") as f:
@@ -378,14 +468,26 @@ def main():
     # from an idle GPU first (the W + K contract by itself), then at the clock the GPU holds under load (the headline)
     idle = None
     if args.wakeup_ms > 0 and not args.no_idle_leg:
-        dt_i, _, k1_i, _ = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, 0.0)
-        dt_i = sharding.allreduce_max(dt_i)
+        dt_i, st_i, _, _, _ = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, 0.0)
+        dt_i = comm.allreduce_max(dt_i)
         idle = {"value": total_frames * W * H * args.steps / dt_i / 1e6, "ms_per_step": dt_i / args.steps * 1e3,
-                "k1_launch_ms_first_median_last": [float(k1_i[0]), float(np.median(k1_i)), float(k1_i[-1])],
+                "step_gpu_ms_first_median_last": [float(st_i[0]), float(np.median(st_i)), float(st_i[-1])],
                 "note": "same W warm-up + K timed steps started from an idle GPU (lowest clock level), measured before the headline"}
-    dt, k0_ms, k1_ms, woke = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, args.wakeup_ms)
-    dt = sharding.allreduce_max(dt)
-    checksum = sharding.allreduce_sum([float(out.double().sum().item()), float(count)])
+    # ---- the headline: K x kde_jbf_process_batch --------------------------------------------------------------------
+    dt, step_ms, _, _, woke = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, args.wakeup_ms)
+    dt = comm.allreduce_max(dt)
+    smooth0 = jbf.getSmoothImage_Device(count)[0].cpu().numpy() if count > 1 else jbf.getSmoothImage_Device().cpu().numpy()
+    out0 = out[0].cpu().numpy()
+    checksum = comm.allreduce_sum([float(out.double().sum().item()), float(count)])
+    # ---- the same K steps as two separate launches: the per-kernel times the roofline object reads -------------------
+    dt_s, _, k0_ms, k1_ms, _ = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, 0.0, split=True)
+    dt_s = comm.allreduce_max(dt_s)
+    split_same = bool(torch.equal(out[0].cpu(), torch.from_numpy(out0)))
+    k1_per_rank = comm.gather_objects(float(np.mean(k1_ms)))
+    # ---- side legs every rank runs on its own GPU (north_star: 640x480 AND 1920x1080 batches at 1/2/4/8 GPUs) --------
+    legs = None
+    if not args.no_extra:
+        legs = reduce_shard_legs(comm.gather_objects(shard_legs(torch, filters, synth, args, barrier)), world)
 
     if rank == 0:
         px_per_launch = count * W * H
@@ -393,52 +495,139 @@ def main():
         names = filters.JointBilateralFilter.variants()
         vname = names[args.variant] if args.variant >= 0 else next((nm for nm in names[1:] if nm.startswith(f"w{p.window_size}-")), None)
         entry, src = pmc_lookup(args.pmc_json, p.window_size, vname)
-        roof = {"bound": "hbm", "bound_measured": "valu-issue",
+        roof = {"bound": "hbm",
                 "limiter": "valu-issue (K1 does 2 exp + ~30 flops per tap against 11 B/pixel; see roofline.valu)",
-                "kernel": "K1 joint_bilateral_filtering"}
+                "kernel": "K1 joint_bilateral_filtering",
+                "measured_in": "the split leg: the same W + K steps issued as kde_jbf_presmooth_batch + kde_jbf_filter_batch right after the "
+                               "headline's K boundary calls, HIP events on the launch stream"}
         roof.update(k1_roofline(px_per_launch, k1_avg_ms, entry, src))
         roof["k0_avg_launch_ms"] = float(np.mean(k0_ms))
         roof["launch_ms_first_min_max"] = [float(k1_ms[0]), float(np.min(k1_ms)), float(np.max(k1_ms))]   # clock ramp shows here
         roof["launch_ms"] = {"mean": k1_avg_ms, "median": float(np.median(k1_ms)), "min": float(np.min(k1_ms)),
                              "max": float(np.max(k1_ms)), "first": float(k1_ms[0])}
+        roof["k1_avg_launch_ms_per_rank"] = k1_per_rank
+        value = total_frames * W * H * args.steps / dt / 1e6
         res = {
             "metric": METRIC,
-            "value": total_frames * W * H * args.steps / dt / 1e6,
+            "value": value,
             "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "wakeup_steps_before_warmup": woke,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"JointBilateralFilter::Process (K0 pre-smooth 5/30/30 + K1) on {total_frames} x {W}x{H} "
                             f"synthetic RGB-D frames ({count} per GPU), window {p.window_size} (radius {p.window_size // 2}), "
                             f"sigma_s {p.spatial_sigma:g} px, sigma_r {p.color_sigma:g}/255, sigma_d {p.depth_sigma:g} mm",
+                "timed_call": "kde_jbf_process_batch, one call per step",
                 "frames_per_gpu": count, "width": W, "height": H, "window": p.window_size,
-                "sharding": f"contiguous frame blocks x{world}, params broadcast from rank 0 ({args.backend if use_dist else 'single process'}"
-                            + (", all ranks on cuda:0" if args.share_device else "") + ")" + (" [REPLICAS ONLY]" if replicas_only else ""),
+                "sharding": sharding_txt,
                 "kernel_variant": (names[args.variant] if args.variant >= 0 else f"auto ({vname})"),
             },
+            "ranks_seen": ranks_seen, "devices": devices, "distinct_devices": len({d.get("pci_bus_id") for d in devices}),
+            "rccl": rccl, "replicas_only": replicas_only,
+            "boundary_vs_split": {"step_gpu_ms_mean": float(np.mean(step_ms)), "step_gpu_ms_median": float(np.median(step_ms)),
+                                  "split_leg_ms_per_step": dt_s / args.steps * 1e3, "split_leg_value": total_frames * W * H * args.steps / dt_s / 1e6,
+                                  "value_over_split_leg_value": value / (total_frames * W * H * args.steps / dt_s / 1e6),
+                                  "k0_plus_k1_ms": float(np.mean(k0_ms) + np.mean(k1_ms)), "outputs_bit_identical": split_same},
             "roofline": roof,
             "checksum": {"sum_filtered_mm": checksum[0], "frames": int(checksum[1])},
         }
         if idle:
             res["from_idle"] = idle
         if not args.no_verify:
-            res["verified"] = verify_frame0(args, p, synth, first, out[0].cpu().numpy(), smooth[0].cpu().numpy(), args.variant)
+            res["verified"] = verify_frame0(args, p, synth, first, out0, smooth0, args.variant)
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(args, synth, args.cpu_seconds)
             res["cpu_baseline_1t"] = cpu_baseline(args, synth, max(3.0, args.cpu_seconds / 2), threads=1)
-        if world == 1 and not args.no_extra:
-            res["also"] = side_measurements(torch, filters, synth, args)
-            res["roofline"]["fhd_w19"] = res["also"].pop("fhd_w19_config3")
+        if legs is not None:
+            fhd = legs.pop("fhd_w19_config3")
+            names19 = next((nm for nm in names[1:] if nm.startswith("w19-")), None)
+            e19, s19 = pmc_lookup(args.pmc_json, 19, names[args.variant] if args.variant >= 0 else names19)
+            fhd.update(k1_roofline(fhd["px_per_gpu"], fhd["k1_avg_launch_ms"], e19, s19), bound="hbm", limiter="valu-issue")
+            res["roofline"]["fhd_w19"] = fhd
+            res["also"] = legs
+            if world == 1:
+                res["also"].update(single_gpu_extras(torch, filters, synth, args))
+                floor = res["also"].get("k1_w19_content_dependence", {}).get("synthetic/noelide")
+                if floor:
+                    fhd["k1_mpix_s_noelide"] = floor["k1_mpix_s"]
+                    fhd["k1_ms_noelide"] = floor["k1_ms"]
         print(json.dumps(res), file=real_stdout, flush=True)
-    if use_dist:
-        dist.destroy_process_group()
+    barrier()           # the other ranks stay until rank 0 has checked and printed
+    comm.close()
 
 
-def side_measurements(torch, filters, synth, args):
-    """not the headline: K1 alone at 1080p / window 19 (BASELINE config 3) and with the reference's
-    compile-time constants (window 5, sigma 70/50/20) on the VGA batch; same event timing."""
+def shard_legs(torch, filters, synth, args, barrier):
+    """the side legs EVERY rank runs on its own GPU, each started together (barrier) and reduced by reduce_shard_legs:
+    BASELINE config 3's pass -- Process on 32 x 1920x1080 per GPU, window 19, the pass north_star's roofline target names --
+    and the config-5 chain on a batch of 64 x 640x480 per GPU through the batched entry points."""
+    out = {}
+    w, h, n, window = 1920, 1080, 32, 19
+    p = filters.JointBilateralFilter.default_params()
+    p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma = window, 3.0, 7.65, 20.0
+    color, depth = make_inputs(synth, torch, 1000, n, w, h, 2)
+    smooth, res = torch.empty_like(color), torch.empty_like(depth)
+    jbf = filters.JointBilateralFilter(w, h, p, max_batch=n)
+    if args.variant >= 0:
+        jbf.set_variant(args.variant)
+    steps = max(3, min(args.steps, 10))
+    dt, _, _, _, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 2, barrier)                 # K x the boundary call
+    _, _, k0, k1, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 1, barrier, split=True)    # its two launches
+    out["fhd_w19_config3"] = {"workload": f"JointBilateralFilter::Process (K0 + K1) on {n} x {w}x{h} per GPU, window {window}, sigma 3/7.65/20 "
+                                          "(BASELINE config 3 as SURVEY 8(d) sizes it: 730 MB of algorithmic traffic per launch)",
+                              "frames": n, "width": w, "height": h, "window": window, "px": n * w * h, "steps": steps, "dt_s": dt,
+                              "k0_ms": float(np.mean(k0)), "k1_ms": float(np.mean(k1))}
+    jbf.close()
+    del color, depth, smooth, res
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_chain_batch", os.path.join(ROOT, "tools", "bench_chain_batch.py"))
+    bcb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bcb)
+    barrier()
+    out["vga_chain_batch64"] = dict(bcb.run(torch, filters, synth, 640, 480, 64, 6), px=64 * 640 * 480)
+    return out
+
+
+def k1_content_legs(torch, filters, names, pre, p, depth, contents, variants, rounds=12, skip=2):
+    """K1 alone on the K0-smoothed guide of each content, every kernel of `variants` ({label: variant name | None}) in
+    interleaved rounds (clock / thermal drift cancels); median launch time per (content, kernel)."""
+    n, h, w = depth.shape
+    res = torch.empty_like(depth)
+    legs = {}
+    for cname, col in contents.items():
+        guide = torch.empty_like(col)
+        pre.presmooth_batch(col, guide)
+        js = {}
+        for label, vname in variants.items():
+            if vname is not None and vname not in names:
+                continue
+            j = filters.JointBilateralFilter(w, h, p, max_batch=n)
+            if vname is not None:
+                j.set_variant(names.index(vname))
+            js[label] = j
+        times = {k: [] for k in js}
+        for rnd in range(rounds):
+            for k, j in js.items():
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_.record()
+                j.filter_batch(depth, guide, res)
+                b_.record()
+                torch.cuda.synchronize()
+                if rnd >= skip:
+                    times[k].append(a_.elapsed_time(b_))
+        for k, tl in times.items():
+            ms = float(np.median(tl))
+            legs[f"{cname}/{k}"] = {"k1_ms": ms, "k1_mpix_s": n * w * h / ms / 1e3}
+        for j in js.values():
+            j.close()
+        del guide
+    return legs
+
+
+def single_gpu_extras(torch, filters, synth, args):
+    """N = 1 only, not the headline: the reference's compile-time constants on the VGA batch, the dependence of K1 on content
+    (windows 11 and 19), this chip's copy ceiling, the single-frame chain of config 5, the feeder; same event timing."""
     out = {}
 
     def run(name, w, h, n, distinct, window, ss, cs, ds):
@@ -450,7 +639,8 @@ def side_measurements(torch, filters, synth, args):
         if args.variant >= 0:
             jbf.set_variant(args.variant)
         steps = max(3, min(args.steps, 10))
-        dt, k0, k1, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 2, lambda: None)
+        dt, _, _, _, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 2, lambda: None)
+        _, _, k0, k1, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 1, lambda: None, split=True)
         px = n * w * h
         k1m = float(np.mean(k1))
         names = filters.JointBilateralFilter.variants()
@@ -462,59 +652,50 @@ def side_measurements(torch, filters, synth, args):
                      "k0_avg_launch_ms": float(np.mean(k0)), "bound": "hbm", "limiter": "valu-issue"}
         out[name].update(k1_roofline(px, k1m, entry, src))
 
-    # BASELINE config 3 as SURVEY 8(d) sizes it: 32 frames = 730 MB of algorithmic traffic, beyond the 256 MB Infinity Cache
-    run("fhd_w19_config3", 1920, 1080, 32, 2, 19, 3.0, 7.65, 20.0)
     run("vga_reference_constants_w5", 640, 480, 64, 8, 5, 70.0, 50.0, 20.0)
-    # ---- the headline's dependence on content (tile-level rule elision fires on smooth tiles only): K1 alone on the
-    # synthetic frames and on the reference's own colour frame (input/color.jpg decode, textured) tiled to the batch,
-    # each with the default kernel and with its "-noelide" twin (every tile runs the full-rule body: the floor)
+    # ---- dependence on content (tile-level rule elision fires on smooth tiles only): K1 alone on the synthetic frames and
+    # on the reference's own colour frame (input/color.jpg decode, textured), each with the default kernel and with its
+    # "-noelide" twin (every tile runs the full-rule body: the data-independent floor)
     try:
         from PIL import Image
         fix = np.ascontiguousarray(np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "color_640x480.png")).convert("RGB"))[..., ::-1])
     except Exception:
         fix = None
     names = filters.JointBilateralFilter.variants()
+    pre = filters.JointBilateralFilter(640, 480, max_batch=64)             # K0 with the reference's 5/30/30, as in the headline step
     p11 = filters.JointBilateralFilter.default_params()
     p11.window_size, p11.spatial_sigma, p11.color_sigma, p11.depth_sigma, p11.presmooth = 11, 3.0, 7.65, 20.0, 0
-    n64 = 64
-    syn_c, syn_d = make_inputs(synth, torch, 0, n64, 640, 480, 8)
+    syn_c, syn_d = make_inputs(synth, torch, 0, 64, 640, 480, 8)
     content = {"synthetic": syn_c}
     if fix is not None:
-        content["reference_colour_frame_x64"] = torch.from_numpy(fix).cuda()[None].repeat(n64, 1, 1, 1).contiguous()
-    res11 = torch.empty_like(syn_d)
-    legs = {}
-    pre = filters.JointBilateralFilter(640, 480, max_batch=n64)            # K0 with the reference's 5/30/30, as in the headline step
-    for cname, col in content.items():
-        guide = torch.empty_like(col)
-        pre.presmooth_batch(col, guide)
-        js = {}
-        for vname in ("auto", "w11-pk2-16x16-false-v4-noelide"):
-            if vname != "auto" and vname not in names:
-                continue
-            j = filters.JointBilateralFilter(640, 480, p11, max_batch=n64)
-            if vname != "auto":
-                j.set_variant(names.index(vname))
-            js["default" if vname == "auto" else "noelide"] = j
-        times = {k: [] for k in js}
-        for rnd in range(12):                                              # interleaved rounds: clock / thermal drift cancels
-            for k, j in js.items():
-                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a_.record()
-                j.filter_batch(syn_d, guide, res11)
-                b_.record()
-                torch.cuda.synchronize()
-                if rnd >= 2:
-                    times[k].append(a_.elapsed_time(b_))
-        for k, tl in times.items():
-            ms = float(np.median(tl))
-            legs[f"{cname}/{k}"] = {"k1_ms": ms, "k1_mpix_s": n64 * 640 * 480 / ms / 1e3}
-        for j in js.values():
-            j.close()
+        content["reference_colour_frame_x64"] = torch.from_numpy(fix).cuda()[None].repeat(64, 1, 1, 1).contiguous()
+    legs = k1_content_legs(torch, filters, names, pre, p11, syn_d, content, {"default": None, "noelide": "w11-pk2-16x16-false-v4-noelide"})
     pre.close()
     out["k1_w11_content_dependence"] = {"workload": "K1 alone on the K0-smoothed guide (as in the headline step), 64 x 640x480, window 11, sigma "
                                                     "3/7.65/20; default kernel (tile-level rule elision) and its -noelide twin (every tile runs the "
                                                     "full-rule body) in interleaved rounds, median of 10", **legs}
-    del content, syn_c, syn_d, res11
+    del content, syn_c, syn_d
+    # the pass north_star's target names: 32 x 1920x1080, window 19.  Textured content = the reference's colour frame tiled
+    # 3 x 2.25 and cropped to 1920x1080; the depth frames are the synthetic ones in both legs
+    pre = filters.JointBilateralFilter(1920, 1080, max_batch=32)
+    p19 = filters.JointBilateralFilter.default_params()
+    p19.window_size, p19.spatial_sigma, p19.color_sigma, p19.depth_sigma, p19.presmooth = 19, 3.0, 7.65, 20.0, 0
+    syn_c, syn_d = make_inputs(synth, torch, 1000, 32, 1920, 1080, 2)
+    content = {"synthetic": syn_c}
+    if fix is not None:
+        big = np.ascontiguousarray(np.tile(fix, (3, 3, 1))[:1080, :1920])
+        content["reference_colour_frame_tiled_1080p_x32"] = torch.from_numpy(big).cuda()[None].repeat(32, 1, 1, 1).contiguous()
+    legs = k1_content_legs(torch, filters, names, pre, p19, syn_d, content, {"default": None, "noelide": "w19-pk1-16x16-false-v4-noelide"},
+                           rounds=6, skip=1)
+    pre.close()
+    for cname in content:
+        a_, b_ = legs.get(f"{cname}/default"), legs.get(f"{cname}/noelide")
+        if a_ and b_:
+            legs[f"{cname}/elision_gain"] = b_["k1_ms"] / a_["k1_ms"] - 1.0
+    out["k1_w19_content_dependence"] = {"workload": "K1 alone on the K0-smoothed guide, 32 x 1920x1080, window 19, sigma 3/7.65/20 (the pass north_star's "
+                                                    "roofline target names); default kernel and its -noelide twin (the data-independent floor) in "
+                                                    "interleaved rounds, median of 5; textured content = the reference's colour frame tiled to 1080p", **legs}
+    del content, syn_c, syn_d
 
     # empirical HBM ceiling: float4 copy of 1 GiB (read + write)
     n = 1 << 28
@@ -568,13 +749,11 @@ def side_measurements(torch, filters, synth, args):
 
     ms = timed(chain)
     out["fhd_full_chain_config5"] = {"ms_per_frame": ms, "mpix_s": W * H / ms / 1e3, "rows": 15, "cols": 20}
-    # the same chain on a BATCH of frames (north_star's unit): every stage takes the whole batch per launch
-    # (kde_jbf_process_batch, kde_rgbf_process_batch), next to the same frames pushed through the single-frame calls
+    # the same chain on a BATCH of 1080p frames (north_star's unit; the 64 x 640x480 batch is a leg every rank runs)
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_chain_batch", os.path.join(ROOT, "tools", "bench_chain_batch.py"))
     bcb = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bcb)
-    out["vga_chain_batch64"] = bcb.run(torch, filters, synth, 640, 480, 64, 6)
     out["fhd_chain_batch8"] = bcb.run(torch, filters, synth, 1920, 1080, 8, 6)
     db = d[None].repeat(32, 1, 1).contiguous()
     pb = torch.empty((32, H, W, 3), dtype=torch.float32, device="cuda")

@@ -9,7 +9,7 @@
 // write on the same C ABI (include/kde_hip.h).
 //
 // usage: shard_replay [--frames N] [--width W] [--height H] [--window 11] [--steps K] [--warmup W] [--wakeup-ms 150]
-//                     [--devices G] [--frames-file F] [--verify]
+//                     [--devices G] [--frames-file F] [--verify] [--force-rccl-failure]
 //   Timing follows bench.py: an untimed wake-up load (an idle MI355X sits at its lowest clock level), W warm-up steps,
 //   then K timed steps that all device threads start together; every step is K0 (kde_jbf_presmooth_batch) + K1
 //   (kde_jbf_filter_batch) -- exactly what kde_jbf_process_batch launches -- bracketed by HIP events on the device's
@@ -18,7 +18,11 @@
 //   the two hosts can be compared on identical input; without it the frames come from the built-in generator.
 //   --verify: the same N frames are also filtered on device 0 alone, as ONE block and as TWO half blocks, and the
 //             per-frame checksums of all three runs must be identical (partition independence, bit for bit).
-// prints one JSON line: per-device times, aggregate Mpixels/s, checksum, "params_broadcast": "rccl" | "single-device".
+//   --force-rccl-failure: behave as if ncclCommInitAll had failed (test of the fallback below).
+// Fallback: if the RCCL communicators cannot be created, nothing is restarted -- every device thread forms the
+// parameter block itself ("replicas only"), compares it with rank 0's copy in host memory, and the line says so with RCCL's error.
+// prints one JSON line: per-device times and PCI addresses, aggregate Mpixels/s, checksum,
+// "params_broadcast": "rccl ncclBroadcast" | "replicas only (...)".
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -66,7 +70,7 @@ namespace {
 struct Options {
     int frames = 64, width = 640, height = 480, window = 11, steps = 20, warmup = 5, devices = 0;
     float spatial_sigma = 3.0f, color_sigma = 7.65f, depth_sigma = 20.0f, wakeup_ms = 150.0f;
-    bool verify = false;
+    bool verify = false, force_rccl_failure = false;
     std::string frames_file;
 };
 
@@ -165,14 +169,20 @@ struct ShardResult {
     int wakeup_steps = 0;
     std::vector<uint64_t> frame_hash;       // one per frame of the shard
     bool table_matches_rank0 = true;
+    std::string pci_bus_id;
 };
 
 // filters frames [first, first + count) on `device`; if comm != nullptr the parameter block comes from rank 0's broadcast
 ShardResult run_shard(const Options& o, int device, int rank, int first, int count, ncclComm_t comm, const kde_jbf_params& root_params,
-                      SpinBarrier* barrier = nullptr)
+                      SpinBarrier* barrier = nullptr, const std::vector<float>* root_block = nullptr)
 {
     ShardResult res;
     KDE_OK_OR_DIE(kde_set_device(device));
+    {
+        char bus[64] = "";
+        KDE_OK_OR_DIE(kde_device_pci_bus_id(bus, sizeof(bus)));
+        res.pci_bus_id = bus;
+    }
     hipStream_t stream;
     HIP_OK(hipStreamCreate(&stream));
     const size_t px = (size_t)o.width * o.height;
@@ -201,6 +211,8 @@ ShardResult run_shard(const Options& o, int device, int rank, int first, int cou
         std::vector<float> mine((size_t)p.window_size * p.window_size);
         KDE_OK_OR_DIE(kde_jbf_spatial_table(jbf, mine.data(), (int)mine.size()));
         if (comm || rank == 0) res.table_matches_rank0 = std::memcmp(mine.data(), blk.data() + 8, mine.size() * sizeof(float)) == 0;
+        // replicas only (no communicator): this rank formed the block itself; rank 0's copy is compared in host memory
+        else if (root_block) res.table_matches_rank0 = std::memcmp(mine.data(), root_block->data() + 8, mine.size() * sizeof(float)) == 0;
     }
     if (count > 0) {
         // ---- this shard's frames, resident in this device's HBM ----
@@ -311,6 +323,7 @@ int main(int argc, char** argv)
         else if (a == "--frames-file") o.frames_file = next();
         else if (a == "--devices") o.devices = std::atoi(next());
         else if (a == "--verify") o.verify = true;
+        else if (a == "--force-rccl-failure") o.force_rccl_failure = true;
         else {
             std::fprintf(stderr, "unknown argument %s\n", a.c_str());
             return 2;
@@ -330,11 +343,26 @@ int main(int argc, char** argv)
     p.color_sigma = o.color_sigma;
     p.depth_sigma = o.depth_sigma;
 
-    // one RCCL communicator per device (single process, one thread per device)
+    // one RCCL communicator per device (single process, one thread per device).  If RCCL does not come up the run goes on
+    // in this process without it: every thread forms the parameter block itself and compares it with rank 0's ("replicas only")
     std::vector<ncclComm_t> comms(G, nullptr);
     std::vector<int> devs(G);
     for (int d = 0; d < G; d++) devs[d] = d;
-    NCCL_OK(ncclCommInitAll(comms.data(), G, devs.data()));
+    std::string broadcast_how = "rccl ncclBroadcast";
+    const ncclResult_t init_rc = o.force_rccl_failure ? ncclSystemError : ncclCommInitAll(comms.data(), G, devs.data());
+    std::vector<float> root_block(kBlockLen, 0.0f);
+    if (init_rc != ncclSuccess) {
+        std::fill(comms.begin(), comms.end(), nullptr);
+        broadcast_how = std::string("replicas only (ncclCommInitAll: ") + (o.force_rccl_failure ? "failure forced by --force-rccl-failure" : ncclGetErrorString(init_rc)) + ")";
+        std::fprintf(stderr, "shard_replay: RCCL unavailable, %s\n", broadcast_how.c_str());
+        KDE_OK_OR_DIE(kde_set_device(0));
+        kde_jbf* probe = nullptr;
+        KDE_OK_OR_DIE(kde_jbf_create(&probe, 8, 8, 1, &p));
+        std::vector<float> table((size_t)p.window_size * p.window_size);
+        KDE_OK_OR_DIE(kde_jbf_spatial_table(probe, table.data(), (int)table.size()));
+        KDE_OK_OR_DIE(kde_jbf_destroy(probe));
+        pack_params(p, table, root_block.data());
+    }
 
     // contiguous blocks of ceil(N / G) frames
     const int per = (o.frames + G - 1) / G;
@@ -346,11 +374,12 @@ int main(int argc, char** argv)
     for (int d = 0; d < G; d++)
         threads.emplace_back([&, d]() {
             const int first = std::min(d * per, o.frames), count = std::min(per, o.frames - first);
-            results[d] = run_shard(o, d, d, first, count, comms[d], p, &barrier);
+            results[d] = run_shard(o, d, d, first, count, comms[d], p, &barrier, &root_block);
         });
     for (auto& t : threads) t.join();
     const double wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    for (int d = 0; d < G; d++) NCCL_OK(ncclCommDestroy(comms[d]));
+    for (int d = 0; d < G; d++)
+        if (comms[d]) NCCL_OK(ncclCommDestroy(comms[d]));
 
     double slowest = 0.0;
     bool tables_ok = true;
@@ -358,10 +387,10 @@ int main(int argc, char** argv)
     std::string per_dev = "[";
     for (int d = 0; d < G; d++) {
         slowest = std::max(slowest, results[d].ms_per_step);
-        char buf[256];
-        std::snprintf(buf, sizeof(buf), "%s{\"device\": %d, \"ms_per_step\": %.4f, \"k0_ms\": %.4f, \"k1_ms\": %.4f, \"k1_ms_median\": %.4f, "
-                      "\"k1_ms_min\": %.4f}", d ? ", " : "", d, results[d].ms_per_step, results[d].k0_ms, results[d].k1_ms,
-                      results[d].k1_ms_median, results[d].k1_ms_min);
+        char buf[384];
+        std::snprintf(buf, sizeof(buf), "%s{\"device\": %d, \"pci_bus_id\": \"%s\", \"ms_per_step\": %.4f, \"k0_ms\": %.4f, \"k1_ms\": %.4f, "
+                      "\"k1_ms_median\": %.4f, \"k1_ms_min\": %.4f}", d ? ", " : "", d, results[d].pci_bus_id.c_str(), results[d].ms_per_step,
+                      results[d].k0_ms, results[d].k1_ms, results[d].k1_ms_median, results[d].k1_ms_min);
         per_dev += buf;
         tables_ok = tables_ok && results[d].table_matches_rank0;
         hashes.insert(hashes.end(), results[d].frame_hash.begin(), results[d].frame_hash.end());
@@ -387,7 +416,7 @@ int main(int argc, char** argv)
                 "\"tables_match_rank0\": %s, \"checksum\": \"%016llx\", \"verified\": %s, \"wall_s\": %.2f}\n",
                 G, o.frames, per, o.width, o.height, o.window, o.steps, o.warmup, results[0].wakeup_steps,
                 o.frames_file.empty() ? "built-in generator" : "frames file (bench.py --dump-frames)", slowest, mpix, per_dev.c_str(),
-                "rccl ncclBroadcast", tables_ok ? "true" : "false",
+                broadcast_how.c_str(), tables_ok ? "true" : "false",
                 (unsigned long long)all, o.verify ? (verified ? "true" : "false") : "null", wall_s);
     return (tables_ok && verified) ? 0 : 1;
 }

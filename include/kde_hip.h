@@ -60,6 +60,10 @@ int kde_device_count(int* count);
 int kde_set_device(int device);
 /* name/arch of the current device, e.g. "gfx950:sramecc+:xnack-"; buf may be NULL to query cu_count only */
 int kde_device_info(char* arch_buf, size_t arch_cap, int* cu_count);
+/* PCI address of the current device ("0000:05:00.0", hipDeviceGetPCIBusId): what tells two GPUs of a node apart.
+ * The reference is single-device (main.cpp:160-163); the sharding hosts put it in their report so that a run
+ * over N devices shows N distinct addresses */
+int kde_device_pci_bus_id(char* buf, size_t cap);
 
 /* ============================================================================================
  * JointBilateralFilter — JointBilateralFilter/JointBilateralFilter.{h,cpp,cu}

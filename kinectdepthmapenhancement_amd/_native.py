@@ -48,6 +48,7 @@ SIGNATURES = {
     "kde_device_count": (_i, [C.POINTER(_i)]),
     "kde_set_device": (_i, [_i]),
     "kde_device_info": (_i, [C.c_char_p, _sz, C.POINTER(_i)]),
+    "kde_device_pci_bus_id": (_i, [C.c_char_p, _sz]),
     "kde_jbf_default_params": (_i, [C.POINTER(JbfParams)]),
     "kde_jbf_create": (_i, [_pp, _i, _i, _i, C.POINTER(JbfParams)]),
     "kde_jbf_destroy": (_i, [_vp]),

@@ -89,6 +89,15 @@ extern "C" int kde_device_info(char* arch_buf, size_t arch_cap, int* cu_count)
     return KDE_OK;
 }
 
+extern "C" int kde_device_pci_bus_id(char* buf, size_t cap)
+{
+    KDE_REQUIRE(buf && cap >= 13, "kde_device_pci_bus_id: a buffer of at least 13 bytes is required");
+    int dev = 0;
+    KDE_HIP_TRY(hipGetDevice(&dev));
+    KDE_HIP_TRY(hipDeviceGetPCIBusId(buf, (int)std::min<size_t>(cap, 64), dev));
+    return KDE_OK;
+}
+
 // =====================================================================================================
 // JointBilateralFilter
 // =====================================================================================================

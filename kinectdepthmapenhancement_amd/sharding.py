@@ -8,6 +8,8 @@ spatial table, plus an optional all-reduce of a few scalars for the report.
 """
 from __future__ import annotations
 
+import datetime
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -96,3 +98,96 @@ def allreduce_max(value: float, device: Optional[torch.device] = None, group=Non
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+class ShardComm:
+    """The process groups of a sharded run (one process per GPU), with SURVEY 8(e)'s fallback built in.
+
+    A gloo group over 127.0.0.1 is always created first: it is the rendezvous, it carries the agreement on whether RCCL is
+    usable, and it is what the run falls back to.  With backend "nccl" every rank then tries to bring up an RCCL group on
+    its own device (`new_group(backend="nccl", device_id=...)` + one all-reduce as a smoke test) INSIDE THE SAME PROCESS;
+    the ranks exchange their outcome over gloo, and RCCL is used for the parameter broadcast, the barriers and the report's
+    reductions only if it came up on EVERY rank.  Otherwise nothing is re-executed or restarted (a process that has touched
+    the GPU must not be replaced): every rank computes the parameter block itself ("replicas only"), the blocks are
+    compared over gloo, `rccl_error` holds the first exception text and the caller flags the run.
+
+    Without RANK in the environment (plain single process) every method is the identity."""
+
+    def __init__(self, backend: str = "nccl", local_rank: int = 0, use_gpu: bool = True, force_rccl_failure: bool = False,
+                 timeout_s: float = 600.0):
+        self.active = "RANK" in os.environ
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if self.active else 1
+        self.rank = int(os.environ.get("RANK", "0")) if self.active else 0
+        self.local_rank = local_rank
+        self.group = None               # the group the broadcast / reductions / barriers use (None = the gloo world group)
+        self.backend_used = "single process"
+        self.rccl_error: Optional[str] = None
+        self.rccl_wanted = backend == "nccl"
+        if not self.active:
+            return
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s))
+        self.backend_used = "gloo"
+        if not self.rccl_wanted:
+            return
+        if not use_gpu and not force_rccl_failure:
+            self.backend_used = "gloo (dry run: RCCL not attempted)"
+            return
+        err, g = None, None
+        try:
+            if force_rccl_failure:
+                raise RuntimeError("RCCL initialisation failure forced by --force-rccl-failure (test of the fallback)")
+            dev = torch.device("cuda", local_rank)
+            g = dist.new_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=timeout_s))
+            t = torch.ones(1, dtype=torch.float64, device=dev)
+            dist.all_reduce(t, group=g)                 # the first collective builds the communicator over xGMI
+            torch.cuda.synchronize(dev)
+            if int(t.item()) != self.world:
+                raise RuntimeError(f"RCCL all-reduce of 1 over {self.world} ranks returned {t.item()}")
+        except Exception as e:          # noqa: BLE001 -- whatever RCCL / HIP raised: the fallback takes it from here
+            err = f"{type(e).__name__}: {e}"[:400]
+        outcome = [None] * self.world
+        dist.all_gather_object(outcome, err)            # over gloo: RCCL is used only if it came up on every rank
+        failed = [(r, e) for r, e in enumerate(outcome) if e]
+        if failed:
+            self.rccl_error = f"rank {failed[0][0]}: {failed[0][1]}" + (f" (+{len(failed) - 1} more ranks)" if len(failed) > 1 else "")
+            self.backend_used = "gloo (RCCL unavailable)"
+        else:
+            self.group, self.backend_used = g, "nccl"
+
+    @property
+    def replicas_only(self) -> bool:
+        return self.rccl_error is not None
+
+    def _device(self):
+        return torch.device("cuda", self.local_rank) if self.group is not None else torch.device("cpu")
+
+    def barrier(self) -> None:
+        if not self.active:
+            return
+        if self.group is not None:
+            dist.barrier(group=self.group, device_ids=[self.local_rank])
+        else:
+            dist.barrier()
+
+    def broadcast_params(self, block: np.ndarray, src: int = 0) -> np.ndarray:
+        return broadcast_params(block, self._device(), src, self.group) if self.active else block.copy()
+
+    def allreduce_sum(self, values: Sequence[float]) -> np.ndarray:
+        return allreduce_sum(values, self._device(), self.group) if self.active else np.asarray(values, np.float64).copy()
+
+    def allreduce_max(self, value: float) -> float:
+        return allreduce_max(value, self._device(), self.group) if self.active else float(value)
+
+    def gather_objects(self, obj) -> list:
+        """every rank's `obj`, on every rank (report data only: goes over the gloo group)"""
+        if not self.active:
+            return [obj]
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
+    def close(self) -> None:
+        if self.active and dist.is_initialized():
+            dist.destroy_process_group()

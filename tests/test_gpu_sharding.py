@@ -54,6 +54,18 @@ def test_cpp_shard_replay_with_rccl_broadcast(torch_cuda):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["verified"] is True and line["tables_match_rank0"] is True
     assert line["params_broadcast"].startswith("rccl") and line["devices"] >= 1 and line["frames"] == 6
+    assert all(len(d["pci_bus_id"]) >= 7 for d in line["per_device"])
+
+
+def test_cpp_shard_replay_goes_on_without_rccl(torch_cuda):
+    """SURVEY 8(e) fallback in the C++ host: no communicator -> same process, every device thread forms the block itself"""
+    exe = os.path.join(ROOT, "examples", "shard_replay")
+    r = subprocess.run([exe, "--frames", "6", "--width", "160", "--height", "120", "--steps", "2", "--verify", "--force-rccl-failure"],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["params_broadcast"].startswith("replicas only") and "forced" in line["params_broadcast"]
+    assert line["verified"] is True and line["tables_match_rank0"] is True and line["mpixels_per_s"] > 0
 
 
 def test_bench_py_launches_two_ranks_itself_and_equals_two_single_runs(torch_cuda):
@@ -76,3 +88,52 @@ def test_bench_py_launches_two_ranks_itself_and_equals_two_single_runs(torch_cud
     assert two["checksum"]["sum_filtered_mm"] == a["checksum"]["sum_filtered_mm"] + b["checksum"]["sum_filtered_mm"]
     assert a["checksum"]["sum_filtered_mm"] != b["checksum"]["sum_filtered_mm"]
     assert two["value"] > 0 and two["scaling"] == "weak"
+    assert two["ranks_seen"] == 2 and len({d["pid"] for d in two["devices"]}) == 2 and two["distinct_devices"] == 1     # one GPU, shared
+    assert two["config"]["timed_call"].startswith("kde_jbf_process_batch") and two["boundary_vs_split"]["outputs_bit_identical"]
+
+
+def _bench(extra, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_four_ranks_carry_the_1080p_and_chain_legs(torch_cuda):
+    """what the one N > 1 run of the driver must deliver: at world > 1 the line still carries the 1080p
+    window-19 pass and the batched chain, every rank having run them on its GPU, reduced like the headline.  Here 4 ranks
+    share the box's one GPU over gloo, so the aggregate is about ONE GPU's rate -- the keys, the reductions and the checksum
+    are what is checked."""
+    j = _bench(["--gpus", "4", "--backend", "gloo", "--share-device", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-verify",
+                "--wakeup-ms", "0", "--frames-per-gpu", "16"])
+    assert j["n_gpus"] == 4 and j["ranks_seen"] == 4 and j["checksum"]["frames"] == 64 and j["rccl"]["wanted"] is False
+    fhd, chain = j["roofline"]["fhd_w19"], j["also"]["vga_chain_batch64"]
+    assert fhd["n_gpus"] == 4 and len(fhd["k1_ms_per_rank"]) == 4 and fhd["window"] == 19 and fhd["width"] == 1920
+    assert fhd["process_mpix_s"] > 0 and 0 < fhd["frac"] < 1 and fhd["k1_avg_launch_ms"] == max(fhd["k1_ms_per_rank"])
+    assert chain["n_gpus"] == 4 and len(chain["batched_ms_per_rank"]) == 4 and chain["frames_bit_identical_to_single_calls"] is True
+    assert "cpu_baseline" not in j and "k1_w19_content_dependence" not in j["also"]          # N = 1 only
+
+
+def test_rccl_failure_on_the_gpu_falls_back_in_process(torch_cuda):
+    """the fallback with real filtering: RCCL "fails" on both ranks, the same two processes go on over gloo, the line is
+    flagged and its checksum equals the healthy run's"""
+    common = ["--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-extra", "--no-verify", "--wakeup-ms", "0", "--frames-per-gpu", "8"]
+    bad = _bench(["--gpus", "2", "--share-device", "--force-rccl-failure"] + common)
+    good = _bench(["--gpus", "2", "--share-device", "--backend", "gloo"] + common)
+    assert bad["replicas_only"] is True and "[REPLICAS ONLY]" in bad["config"]["sharding"] and bad["rccl"]["ok"] is False
+    assert good["replicas_only"] is False
+    assert bad["checksum"] == good["checksum"] and bad["value"] > 0
+
+
+def test_one_rank_under_a_launcher_brings_rccl_up(torch_cuda):
+    """N = 1 through the distributed path (what torch.distributed.run gives a rank): the RCCL group really is created on the
+    box's GPU, the broadcast and the reductions go through it, and the line names the device by its PCI address"""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
+                        "--no-extra", "--no-verify", "--wakeup-ms", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["rccl"] == {"wanted": True, "ok": True, "backend_used": "nccl", "error": None, "ranks_whose_block_differs_from_rank0": 0}
+    assert j["ranks_seen"] == 1 and j["devices"][0]["arch"].startswith("gfx950") and len(j["devices"][0]["pci_bus_id"]) >= 7
+    assert j["replicas_only"] is False and "(nccl)" in j["config"]["sharding"]

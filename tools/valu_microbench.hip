@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #define CHECK(x)                                                                                   \
@@ -28,30 +29,154 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int kUnroll = 32;    // instructions (or instruction groups) per loop trip
 
-enum Kind { FMA, PK_FMA, PK_MUL, PK_ADD, EXP, RCP, DOT4, LSHL_ADD, ADD_U32, CNDMASK, CNDMASK_SGPR, CMP_CNDMASK, MUL_F32, CVT_I32, MAX_F32,
-            MIX_EXP_4PK, MIX_EXP_2PK, MIX_EXP_1PK, MIX_DOT_LSHL_PK, MIX_K1_PASS1, NKINDS };
-const char* kNames[NKINDS] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_exp_f32", "v_rcp_f32",
-                              "v_dot4_u32_u8", "v_lshl_add_u32", "v_add_u32", "v_cndmask_b32 (vcc)", "v_cndmask_b32_e64 (sgpr pair)",
-                              "v_cmp_lt_f32 + v_cndmask_b32 (per instruction)", "v_mul_f32", "v_cvt_i32_f32", "v_max_f32",
-                              "1 v_exp_f32 + 4 v_pk_fma_f32", "1 v_exp_f32 + 2 v_pk_fma_f32", "1 v_exp_f32 + 1 v_pk_fma_f32",
-                              "1 v_dot4 + 1 v_lshl_add + 1 v_pk_fma", "K1 pass-1 unit: 2 dot4 + 2 lshl_add + 2 exp + 6 pk"};
-const int kPerGroup[NKINDS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 5, 3, 2, 3, 12};
+// ---- the instruction kinds: X(id, label, instructions per group, code).  Eight independent chains per register class
+// (a: float, p: float pair, u: uint32, d: double) so that no instruction waits for the previous one.  A label that is a
+// single mnemonic is a pure kind: tools/valu_costs.py turns those rows into the cost table (profiles/valu_costs.json)
+// that tools/isa_slots.py and tools/pmc_report.py price a kernel's instruction mix with.
+#define J ((i + 1) & 7)
+#define K2 ((i + 2) & 7)
+#define KINDS(X)                                                                                                                  \
+    X(FMA, "v_fma_f32", 1, asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));)                            \
+    X(FMAC, "v_fmac_f32", 1, asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));)                         \
+    X(MUL_F32, "v_mul_f32", 1, asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));)                                    \
+    X(ADD_F32, "v_add_f32", 1, asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));)                                    \
+    X(SUB_F32, "v_sub_f32", 1, asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));)                                    \
+    X(MAX_F32, "v_max_f32", 1, asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));)                                    \
+    X(MIN_F32, "v_min_f32", 1, asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));)                                    \
+    X(MIN3_F32, "v_min3_f32", 1, asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));)                     \
+    X(MED3_F32, "v_med3_f32", 1, asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));)                     \
+    X(FRACT, "v_fract_f32", 1, asm volatile("v_fract_f32 %0, %0" : "+v"(a[i]));)                                                \
+    X(RNDNE, "v_rndne_f32", 1, asm volatile("v_rndne_f32 %0, %0" : "+v"(a[i]));)                                                \
+    X(MOV, "v_mov_b32", 1, asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(a[J]));)                                          \
+    X(PK_MOV, "v_pk_mov_b32", 1, asm volatile("v_pk_mov_b32 %0, %1, %2" : "=v"(p[i]) : "v"(p[J]), "v"(p[K2]));)                  \
+    X(PK_FMA, "v_pk_fma_f32", 1, asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));)                 \
+    X(PK_MUL, "v_pk_mul_f32", 1, asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pc0));)                              \
+    X(PK_ADD, "v_pk_add_f32", 1, asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pc1));)                              \
+    X(EXP, "v_exp_f32", 1, asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));)                                                      \
+    X(RCP, "v_rcp_f32", 1, asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));)                                                      \
+    X(RSQ, "v_rsq_f32", 1, asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));)                                                      \
+    X(SQRT, "v_sqrt_f32", 1, asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i]));)                                                   \
+    X(DOT4, "v_dot4_u32_u8", 1, asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[J]), "v"(u[K2]));)              \
+    X(SAD_U8, "v_sad_u8", 1, asm volatile("v_sad_u8 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[J]), "v"(u[K2]));)                      \
+    X(PERM, "v_perm_b32", 1, asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[J]), "v"(u[K2]));)                    \
+    X(BFE, "v_bfe_u32", 1, asm volatile("v_bfe_u32 %0, %0, 3, 8" : "+v"(u[i]));)                                                \
+    X(LSHL_ADD, "v_lshl_add_u32", 1, asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[i]) : "v"(u[J]));)                    \
+    X(ADD_LSHL, "v_add_lshl_u32", 1, asm volatile("v_add_lshl_u32 %0, %0, %1, 1" : "+v"(u[i]) : "v"(u[J]));)                    \
+    X(LSHL_OR, "v_lshl_or_b32", 1, asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(u[i]) : "v"(u[J]));)                       \
+    X(ADD3, "v_add3_u32", 1, asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[J]), "v"(u[K2]));)                    \
+    X(LSHL_ADD_U64, "v_lshl_add_u64", 1, asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(q[i & 3]) : "v"(q[(i + 1) & 3]));)    \
+    X(MAD_U64_U32, "v_mad_u64_u32", 1, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[i & 3]) : "v"(u[i]), "v"(u[J]) : "vcc");) \
+    X(ADD_U32, "v_add_u32", 1, asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));)                                  \
+    X(SUB_U32, "v_sub_u32", 1, asm volatile("v_sub_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));)                                  \
+    X(AND_B32, "v_and_b32", 1, asm volatile("v_and_b32 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));)                                  \
+    X(OR_B32, "v_or_b32", 1, asm volatile("v_or_b32 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));)                                     \
+    X(XOR_B32, "v_xor_b32", 1, asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));)                                  \
+    X(LSHLREV, "v_lshlrev_b32", 1, asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(u[i]));)                                       \
+    X(LSHRREV, "v_lshrrev_b32", 1, asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(u[i]));)                                       \
+    X(ASHRREV, "v_ashrrev_i32", 1, asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(u[i]));)                                       \
+    X(MIN_U32, "v_min_u32", 1, asm volatile("v_min_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));)                                  \
+    X(MAX_U32, "v_max_u32", 1, asm volatile("v_max_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));)                                  \
+    X(MAX_I32, "v_max_i32", 1, asm volatile("v_max_i32 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));)                                  \
+    X(MUL_U24, "v_mul_u32_u24", 1, asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));)                          \
+    X(MAD_U24, "v_mad_u32_u24", 1, asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[J]), "v"(u[K2]));)           \
+    X(MUL_LO, "v_mul_lo_u32", 1, asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));)                             \
+    X(MUL_HI, "v_mul_hi_u32", 1, asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));)                             \
+    X(SDWA_ADD, "v_add_u32_sdwa", 1, asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "+v"(u[i]) : "v"(u[J]));) \
+    X(SDWA_MIN, "v_min_u32_sdwa", 1, asm volatile("v_min_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(u[i]) : "v"(u[J]));) \
+    X(DPP_MOV, "v_mov_b32_dpp", 1, asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(u[i]) : "v"(u[J]));) \
+    X(CVT_I32, "v_cvt_i32_f32", 1, asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(u[i]) : "v"(a[i]));)                              \
+    X(CVT_U32, "v_cvt_u32_f32", 1, asm volatile("v_cvt_u32_f32 %0, %1" : "=v"(u[i]) : "v"(a[i]));)                              \
+    X(CVT_F32_U32, "v_cvt_f32_u32", 1, asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(a[i]) : "v"(u[i]));)                          \
+    X(CVT_F32_I32, "v_cvt_f32_i32", 1, asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(a[i]) : "v"(u[i]));)                          \
+    X(CVT_UBYTE, "v_cvt_f32_ubyte1", 1, asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(a[i]) : "v"(u[i]));)                      \
+    X(CVT_PK_U8, "v_cvt_pk_u8_f32", 1, asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(u[i]) : "v"(a[i]));)                 \
+    X(CNDMASK_SGPR, "v_cndmask_b32_e64", 1, asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a[i]) : "v"(c0));)      \
+    X(CMP_E32, "v_cmp_lt_f32_e32", 1, asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(c0) : "vcc");)             \
+    X(CMP_E64, "v_cmp_ge_f32_e64", 1, asm volatile("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m64) : "v"(a[i]), "v"(c0));)             \
+    X(CMP_I32, "v_cmp_gt_i32_e32", 1, asm volatile("v_cmp_gt_i32_e32 vcc, %0, %1" : : "v"(u[i]), "v"(u[J]) : "vcc");)           \
+    X(CMP_CLASS, "v_cmp_class_f32_e32", 1, asm volatile("v_cmp_class_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(u[J]) : "vcc");)    \
+    X(CMP_CNDMASK, "v_cmp_lt_f32 + v_cndmask_b32 (per instruction)", 2,                                                           \
+      asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(c0) : "vcc");                                               \
+      asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[J]) : "v"(c0) : "vcc");)                                             \
+    X(READLANE, "v_readlane_b32", 1, asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sx) : "v"(u[i]));)                           \
+    X(READFIRST, "v_readfirstlane_b32", 1, asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sx) : "v"(u[i]));)                  \
+    X(MBCNT, "v_mbcnt_lo_u32_b32", 1, asm volatile("v_mbcnt_lo_u32_b32 %0, -1, %0" : "+v"(u[i]));)                              \
+    X(ACC_WRITE, "v_accvgpr_write_b32", 1, asm volatile("v_accvgpr_write_b32 a4, %0" : : "v"(u[i]) : "a4");)                \
+    X(ACC_READ, "v_accvgpr_read_b32", 1, asm volatile("v_accvgpr_read_b32 %0, a4" : "=v"(u[i]) : : "a4");)                   \
+    X(DIV_SCALE, "v_div_scale_f32", 1, asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(a[i]) : "v"(c0) : "vcc");)      \
+    X(DIV_FMAS, "v_div_fmas_f32", 1, asm volatile("v_div_fmas_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1) : "vcc");)     \
+    X(DIV_FIXUP, "v_div_fixup_f32", 1, asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));)          \
+    X(FMA_F64, "v_fma_f64", 1, asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i & 3]) : "v"(dc0), "v"(dc1));)                  \
+    X(MUL_F64, "v_mul_f64", 1, asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i & 3]) : "v"(dc0));)                               \
+    X(ADD_F64, "v_add_f64", 1, asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i & 3]) : "v"(dc1));)                               \
+    X(MIX_EXP_4PK, "1 v_exp_f32 + 4 v_pk_fma_f32", 5,                                                                             \
+      asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));                                                                             \
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));                                             \
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[J]) : "v"(pc0), "v"(pc1));                                             \
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[K2]) : "v"(pc0), "v"(pc1));                                            \
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 3) & 7]) : "v"(pc0), "v"(pc1));)                                  \
+    X(MIX_EXP_2PK, "1 v_exp_f32 + 2 v_pk_fma_f32", 3,                                                                             \
+      asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));                                                                             \
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));                                             \
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[J]) : "v"(pc0), "v"(pc1));)                                            \
+    X(MIX_EXP_1PK, "1 v_exp_f32 + 1 v_pk_fma_f32", 2,                                                                             \
+      asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));                                                                             \
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));)                                            \
+    X(MIX_FMA_PK, "1 v_fma_f32 + 1 v_pk_fma_f32", 2,                                                                              \
+      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));                                                  \
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));)                                            \
+    X(MIX_ADDU_FMA, "1 v_add_u32 + 1 v_fma_f32", 2,                                                                               \
+      asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));                                                             \
+      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));)                                                 \
+    X(MIX_DOT_LSHL_PK, "1 v_dot4 + 1 v_lshl_add + 1 v_pk_fma", 3,                                                                 \
+      asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[J]), "v"(u[K2]));                                         \
+      asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[(i + 3) & 7]) : "v"(u[(i + 4) & 7]));                                 \
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));)                                            \
+    X(MIX_K1_PASS1, "K1 pass-1 unit: 2 dot4 + 2 lshl_add + 2 exp + 6 pk", 12,                                                     \
+      asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[J]), "v"(u[K2]));                                         \
+      asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(u[(i + 3) & 7]) : "v"(u[J]), "v"(u[K2]));                               \
+      asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[(i + 4) & 7]) : "v"(u[(i + 5) & 7]));                                 \
+      asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[(i + 6) & 7]) : "v"(u[(i + 5) & 7]));                                 \
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pc1));                                                           \
+      asm volatile("v_pk_add_f32 %0, %0, %1 clamp" : "+v"(p[J]) : "v"(pc1));                                                     \
+      asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[K2]) : "v"(pc0));                                                          \
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 3) & 7]) : "v"(pc0), "v"(pc1));                                   \
+      asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));                                                                             \
+      asm volatile("v_exp_f32 %0, %0" : "+v"(a[J]));                                                                             \
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 4) & 7]) : "v"(pc0), "v"(pc1));                                   \
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 5) & 7]) : "v"(pc0), "v"(pc1));)
+
+#define X(id, label, grp, ...) id,
+enum Kind { KINDS(X) NKINDS };
+#undef X
+#define X(id, label, grp, ...) label,
+const char* kNames[NKINDS] = {KINDS(X)};
+#undef X
+#define X(id, label, grp, ...) grp,
+const int kPerGroup[NKINDS] = {KINDS(X)};
+#undef X
 
 template <int KIND>
 __global__ void bench(uint64_t* ticks, float* sink, float seed, int reps)
 {
-    // eight independent chains per kind so that no instruction waits for the previous one
     float a[8];
     f2 p[8];
     uint32_t u[8];
+    uint64_t q[4];
+    double d[4];
+    uint64_t m64 = 0;
+    uint32_t sx = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         a[i] = seed + (float)i * 0.001f + (float)threadIdx.x * 1e-6f;
         p[i] = f2{a[i], a[i] + 0.5f};
         u[i] = (uint32_t)threadIdx.x * 2654435761u + i;
+        q[i & 3] = (uint64_t)u[i] * 0x9E3779B97F4A7C15ull;
+        d[i & 3] = (double)a[i];
     }
     const float c0 = seed * 0.999f, c1 = seed * 1e-3f;
     const f2 pc0 = f2{c0, c0}, pc1 = f2{c1, c1};
+    const double dc0 = (double)c0, dc1 = (double)c1;
     __syncthreads();
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -60,66 +185,17 @@ __global__ void bench(uint64_t* ticks, float* sink, float seed, int reps)
 #pragma unroll
         for (int k = 0; k < kUnroll; k++) {
             const int i = k & 7;
-            if (KIND == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));
-            if (KIND == PK_FMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));
-            if (KIND == PK_MUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pc0));
-            if (KIND == PK_ADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pc1));
-            if (KIND == EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
-            if (KIND == RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
-            if (KIND == DOT4) asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
-            if (KIND == LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
-            if (KIND == ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
-            if (KIND == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c0));
-            if (KIND == MAX_F32) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
-            if (KIND == CNDMASK_SGPR) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a[i]) : "v"(c0));
-            if (KIND == CMP_CNDMASK) {
-                asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(c0) : "vcc");
-                asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[(i + 1) & 7]) : "v"(c0) : "vcc");
-            }
-            if (KIND == MUL_F32) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
-            if (KIND == CVT_I32) asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(u[i]) : "v"(a[i]));
-            if (KIND == MIX_EXP_4PK) {
-                asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
-                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));
-                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 1) & 7]) : "v"(pc0), "v"(pc1));
-                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 2) & 7]) : "v"(pc0), "v"(pc1));
-                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 3) & 7]) : "v"(pc0), "v"(pc1));
-            }
-            if (KIND == MIX_EXP_2PK) {
-                asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
-                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));
-                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 1) & 7]) : "v"(pc0), "v"(pc1));
-            }
-            if (KIND == MIX_EXP_1PK) {
-                asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
-                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));
-            }
-            if (KIND == MIX_DOT_LSHL_PK) {
-                asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
-                asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[(i + 3) & 7]) : "v"(u[(i + 4) & 7]));
-                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));
-            }
-            if (KIND == MIX_K1_PASS1) {
-                asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
-                asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(u[(i + 3) & 7]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
-                asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[(i + 4) & 7]) : "v"(u[(i + 5) & 7]));
-                asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[(i + 6) & 7]) : "v"(u[(i + 5) & 7]));
-                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pc1));
-                asm volatile("v_pk_add_f32 %0, %0, %1 clamp" : "+v"(p[(i + 1) & 7]) : "v"(pc1));
-                asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[(i + 2) & 7]) : "v"(pc0));
-                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 3) & 7]) : "v"(pc0), "v"(pc1));
-                asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
-                asm volatile("v_exp_f32 %0, %0" : "+v"(a[(i + 1) & 7]));
-                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 4) & 7]) : "v"(pc0), "v"(pc1));
-                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 5) & 7]) : "v"(pc0), "v"(pc1));
-            }
+#define X(id, label, grp, ...) \
+    if constexpr (KIND == id) { __VA_ARGS__ }
+            KINDS(X)
+#undef X
         }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    float s = 0.0f;
+    float s = (float)(m64 & 1) + (float)sx;
 #pragma unroll
-    for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y + (float)u[i];
+    for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y + (float)u[i] + (float)q[i & 3] + (float)d[i & 3];
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
     if ((threadIdx.x & 63) == 0) ticks[wave] = t1 - t0;
     if (s == 12345.678f) sink[0] = s;      // keeps every chain live
@@ -170,8 +246,9 @@ int run_kind(int cus, uint64_t* d_ticks, float* d_sink, std::vector<uint64_t>& h
     return 0;
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    const char* only = argc > 1 ? argv[1] : nullptr;      // optional: only the kinds whose label contains this text
     int dev = 0, cus = 0, clk = 0;
     CHECK(hipGetDevice(&dev));
     CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -188,25 +265,9 @@ int main()
     printf("#   (instructions per wave x waves per SIMD) -- what a roofline needs; ticks/ns = the two clocks' ratio (2.4 = s_memtime\n");
     printf("#   counts 2.4 GHz shader cycles and the waves of a SIMD span the whole launch)\n");
     printf("# columns: 1, 2, 3, 4, 5, 6, 8 waves per SIMD (256-thread blocks, one wave per SIMD each)\n");
-    if (run_kind<FMA>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<PK_FMA>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<PK_MUL>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<PK_ADD>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<EXP>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<RCP>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<DOT4>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<LSHL_ADD>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<ADD_U32>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<CNDMASK>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<CNDMASK_SGPR>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<CMP_CNDMASK>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<MUL_F32>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<CVT_I32>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<MAX_F32>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<MIX_EXP_4PK>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<MIX_EXP_2PK>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<MIX_EXP_1PK>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<MIX_DOT_LSHL_PK>(cus, d_ticks, d_sink, h)) return 1;
-    if (run_kind<MIX_K1_PASS1>(cus, d_ticks, d_sink, h)) return 1;
+#define X(id, label, grp, ...) \
+    if ((only == nullptr || std::strstr(label, only)) && run_kind<id>(cus, d_ticks, d_sink, h)) return 1;
+    KINDS(X)
+#undef X
     return 0;
 }
