@@ -18,12 +18,13 @@ One JSON line is printed by rank 0; besides the contract fields it carries
   roofline     — the dominant kernel (K1) against the HBM roofline: algorithmic 11 B/pixel
                  (4 B depth read + 3 B packed-BGR guide read + 4 B filtered write) x pixels per launch
                  / its average launch duration, measured with HIP events on the launch stream
-                 inside the timed region.  K1 is instruction-issue bound, not HBM-bound, so the object also
-                 carries `valu`: issue slots per second against the chip's peak (1024 SIMDs x clock / 4 cycles; a
-                 transcendental takes two slots), with the per-wave instruction counts from the committed PMC
-                 profile of exactly this code (profiles/pmc_bench.json, matched by a hash of the kernel sources)
-                 and the launch time measured live; and `fhd_w19`: the same figures for the pass north_star's
-                 roofline target names (32 x 1920x1080, window 19; BASELINE config 3);
+                 (the split leg).  K1 is instruction-issue bound, not HBM-bound, so the object also carries
+                 `valu.mix_ceiling`: the time the kernel's VALU instructions alone need -- its own mix priced with the
+                 MEASURED issue cost of every opcode (tools/valu_microbench -> profiles/valu_costs.json; tools/valu_mix.py
+                 on the committed PMC counts of exactly this code, profiles/pmc_bench.json, matched by a hash of the kernel
+                 sources) -- over the launch time measured live; and `fhd_w19`: the same figures for the pass north_star's
+                 roofline target names (32 x 1920x1080, window 19; BASELINE config 3), run by every rank, with
+                 `k1_mpix_s_noelide` = its data-independent floor;
   verified     — frame 0 of the TIMED output checked after the timed region, stage by stage (oracle.stage_check): the
                  stage build of the library (tools/hooks/libkde_hip_stage.so: same sources + dumps) must reproduce it to
                  the bit, its first-pass average is held to the float32 first-order bound of the binary64 average, and
@@ -53,8 +54,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROAR
 K1_BYTES_PER_PX = 11.0
 CLK_GHZ = 2.4                  # max shader clock (same guide)
 N_SIMD = 1024                  # 256 CUs x 4
-SLOT_CYCLES = 4.0              # one wave64 VALU instruction per 4 cycles per SIMD (a transcendental: 8), the model
-                               # DESIGN.md prices K1 with; profiles/r02_valu_microbench.txt has the measured costs
+SLOT_CYCLES = 4.0              # r01-r03's nominal slot model, kept as a comparison figure only: gfx950 issues v_mul / v_add / v_fma_f32 in
+                               # 2 cycles, so "4 cycles per instruction" is not a ceiling; roofline.valu.mix_ceiling prices the real mix
 
 
 def parse():
@@ -174,24 +175,31 @@ def pmc_lookup(path, window, variant_name=None):
 
 
 def k1_roofline(px_per_launch, k1_ms, entry, src):
-    """HBM roofline (the contract's fields) + the VALU issue-slot roofline of one K1 launch"""
+    """HBM roofline (the contract's fields) + the VALU-issue ceiling of one K1 launch: the kernel's own instruction mix priced
+    with the measured issue cost of every opcode (tools/valu_mix.py on the committed PMC counts of exactly this code; costs from
+    tools/valu_microbench, profiles/valu_costs.json) against the launch time measured live."""
     achieved = K1_BYTES_PER_PX * px_per_launch / (k1_ms * 1e-3) / 1e9
     r = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
          "traffic": None, "algorithmic_bytes_per_launch": K1_BYTES_PER_PX * px_per_launch, "avg_launch_ms": k1_ms}
-    peak_slots = N_SIMD * CLK_GHZ * 1e9 / SLOT_CYCLES
-    valu = {"peak_slots_per_s": peak_slots, "clk_ghz": CLK_GHZ, "achieved_slots_per_s": None, "frac": None, "profile": src,
-            "definition": "slots per launch = (SQ_INSTS_VALU + SQ_INSTS_VALU_TRANS_F32) of the profiled launch of this grid "
-                          "(wave-instructions; a transcendental takes two 4-cycle slots) / live launch time; "
-                          "peak = 1024 SIMDs x clk / 4"}
+    valu = {"mix_ceiling": None, "profile": src,
+            "definition": "mix_ceiling = bare_stream_ms / live launch ms; bare_stream_ms = sum over VALU opcodes of (instructions per wave x measured "
+                          "issue cost: 2-cycle class ~1.0-1.1 ns, 4-cycle class ~1.75-1.8 ns, transcendentals 3.41 ns per wave-instruction per "
+                          "SIMD) x waves / 1024 SIMDs -- what the kernel's VALU instructions alone take with every SIMD issuing back to back; "
+                          "<= 1 by construction (the costs are the cheapest each opcode gets at any occupancy)"}
     if entry:
-        d, c = entry["derived"], entry["counters"]
+        d, c, mix = entry["derived"], entry["counters"], entry.get("mix")
         r["traffic"] = d.get("hbm_bytes")
+        if mix:
+            bare_ms = mix["bare_stream_ns"] * 1e-6
+            valu.update(mix_ceiling=bare_ms / k1_ms, bare_stream_ms=bare_ms, mean_ns_per_instruction=mix["mean_ns_per_instruction"],
+                        class_fractions=mix["class_fractions"], not_in_cost_table_frac=mix["not_in_cost_table_frac"])
         if "SQ_INSTS_VALU" in c:
             slots = c["SQ_INSTS_VALU"] + c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
-            valu.update(achieved_slots_per_s=slots / (k1_ms * 1e-3), frac=slots / (k1_ms * 1e-3) / peak_slots,
-                        valu_insts_per_wave=d.get("valu_insts_per_wave"), trans_insts_per_wave=d.get("trans_insts_per_wave"),
-                        waves=c.get("SQ_WAVES"), grid=entry["grid"], vgprs=entry.get("vgprs"),
-                        pmc_busy_frac=d.get("valu_busy"), pmc_waves_per_simd=d.get("waves_per_simd"))
+            valu.update(valu_insts_per_wave=d.get("valu_insts_per_wave"), trans_insts_per_wave=d.get("trans_insts_per_wave"),
+                        waves=c.get("SQ_WAVES"), grid=entry["grid"], vgprs=entry.get("vgprs"), pmc_waves_per_simd=d.get("waves_per_simd"),
+                        nominal_4cycle_slot_frac=slots / (k1_ms * 1e-3) / (N_SIMD * CLK_GHZ * 1e9 / SLOT_CYCLES),
+                        nominal_4cycle_slot_note="r01-r03's model (every VALU instruction one 4-cycle slot, a transcendental two, at 2.4 GHz): "
+                                                 "not a ceiling for kernels with 2-cycle opcodes; kept for comparison")
     r["valu"] = valu
     return r
 
@@ -224,6 +232,7 @@ def verify_frame0(args, p, synth, first_seed, out0, smooth0, variant):
     return {"ok": bool(k0_exact and same and not r["bad"].any() and not chk["bad"].any()), "frame": 0, "pixels": r["n"],
             "k0_u8_exact": k0_exact, "stage_build_bit_identical": same,
             "stagewise": {"bad": int(r["bad"].sum()), "band_pixels": r["band"], "band_frac": r["band_frac"],
+                          "band_decision_pixels": r["band_decision"], "grid_pixels": r["grid"], "avg_checked_of_strict": r["avg_checked_of_strict"],
                           "max_rel_err_strict": r["max_rel_strict"], "avg_checked": r["avg_checked"],
                           "avg_err_over_bound_p50_p99_max": [r["avg_bound_frac_p50"], r["avg_bound_frac_p99"], r["avg_bound_frac_max"]],
                           "avg_bound_rel_p50_max": [r["avg_tol_p50"], r["avg_tol_max"]],
@@ -475,14 +484,16 @@ def main():
                 "note": "same W warm-up + K timed steps started from an idle GPU (lowest clock level), measured before the headline"}
     # ---- the headline: K x kde_jbf_process_batch --------------------------------------------------------------------
     dt, step_ms, _, _, woke = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, args.wakeup_ms)
-    dt = comm.allreduce_max(dt)
+    # ---- the same K steps as two separate launches, right behind it (no idle gap: the clock stays where it is), into
+    # buffers of their own: the per-kernel times the roofline object reads ------------------------------------------
+    out2 = torch.empty_like(out)
+    dt_s, _, k0_ms, k1_ms, _ = time_steps(torch, jbf, depth, color, smooth, out2, args.steps, args.warmup, barrier, 0.0, split=True)
+    dt, dt_s = comm.allreduce_max(dt), comm.allreduce_max(dt_s)
+    split_same = bool(torch.equal(out2, out))
+    del out2
     smooth0 = jbf.getSmoothImage_Device(count)[0].cpu().numpy() if count > 1 else jbf.getSmoothImage_Device().cpu().numpy()
     out0 = out[0].cpu().numpy()
     checksum = comm.allreduce_sum([float(out.double().sum().item()), float(count)])
-    # ---- the same K steps as two separate launches: the per-kernel times the roofline object reads -------------------
-    dt_s, _, k0_ms, k1_ms, _ = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, 0.0, split=True)
-    dt_s = comm.allreduce_max(dt_s)
-    split_same = bool(torch.equal(out[0].cpu(), torch.from_numpy(out0)))
     k1_per_rank = comm.gather_objects(float(np.mean(k1_ms)))
     # ---- side legs every rank runs on its own GPU (north_star: 640x480 AND 1920x1080 batches at 1/2/4/8 GPUs) --------
     legs = None

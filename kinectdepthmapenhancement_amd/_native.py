@@ -61,6 +61,7 @@ SIGNATURES = {
     "kde_jbf_smooth_device": (_i, [_vp, _pp]),
     "kde_jbf_spatial_table": (_i, [_vp, _vp, _i]),
     "kde_jbf_set_variant": (_i, [_vp, _i]),
+    "kde_jbf_active_variant": (_i, [_vp, C.POINTER(_i)]),
     "kde_jbf_variant_count": (_i, []),
     "kde_jbf_variant_name": (C.c_char_p, [_i]),
     "kde_mrf_create": (_i, [_pp, _i, _i, _i, _i, _f, _f]),

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
                 o.l = -1;
                 o.d = 0.0f;
             }
-            if (!FIRST || sets.write_ld) cs.ld[p] = o;
+            if (sets.write_ld) cs.ld[p] = o;      // (a kernel argument: uniform; the last step of a pipeline stores no records)
             cs.labels[p] = o.l;
         }
     };

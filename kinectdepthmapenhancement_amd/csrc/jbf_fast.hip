@@ -55,7 +55,9 @@ struct FastArgs {
     // log2 of the spatial table (zeros of the table -> factor skipped -> log2 = 0).  Scalar kernels read
     // tab[i*WIN + j]; packed kernels read the pair (ls[i][j of p0], ls[i][j of p1]) of unit u at
     // tab[(i*WIN + u)*2 .. +1], so the addend of the argument fma is one aligned SGPR pair.
-    __attribute__((aligned(8))) float tab[722];
+    // 21 x 21 x 2 floats: the widest tuned window.  The whole struct is the kernel's argument block and stays below HIP's 4 KB
+    // limit for it (window 23 would need 4232 bytes for the table alone): wider windows take the generic kernel
+    __attribute__((aligned(8))) float tab[882];
 };
 
 __device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c)
@@ -708,7 +710,18 @@ const Variant kVariants[] = {
     K(19, 1, 16, 16, false), KS(19, 1, 16, 16, false), KS(19, 2, 16, 16, false), K(19, 2, 16, 16, false), K(19, 1, 32, 8, false),
     KS(19, 1, 32, 8, false), KS(19, 2, 32, 8, false), V(19, 2, 16, 16, false), V(19, 1, 32, 8, false),
     KN(19, 1, 16, 16, false),
+    // r04: the other windows the ABI accepts (kde_jbf_params.window_size is a run-time argument in the reference,
+    // JointBilateralFilter.cu:10,18-19) up to the widest whose log2(S) table fits the kernel-argument block.  Same kernel
+    // template, vector loader; the pass-1 arguments stay in registers at window 3 and are recomputed from window 9 on.
+    // First listed = built-in choice (tools/sweep_jbf.py, profiles/r04_sweep_k1_windows.log)
+    K(3, 1, 16, 16, true),   K(3, 2, 16, 16, true),
+    K(9, 2, 16, 16, false),  K(9, 1, 16, 16, false),
+    K(13, 2, 16, 16, false), K(13, 1, 16, 16, false),
+    K(15, 1, 16, 16, false), K(15, 2, 16, 16, false),
+    K(17, 1, 16, 16, false), K(17, 2, 16, 16, false),
+    K(21, 1, 16, 16, false), K(21, 2, 16, 16, false),
 };
+static_assert(sizeof(FastArgs) <= 4096, "FastArgs is passed by value as the kernel-argument block");
 #undef V
 #undef K
 #undef KS

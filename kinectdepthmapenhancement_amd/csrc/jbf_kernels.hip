@@ -675,6 +675,14 @@ __global__ __launch_bounds__(kThreads) void mrf_kernel(MrfDev a)
 int jbf_variant_count() { return 1 + jbf_fast_variant_count(); }
 const char* jbf_variant_name(int v) { return v == 0 ? "generic-32x8-1px" : jbf_fast_variant_name(v - 1); }
 
+// the public variant id launch_jbf() will run for these parameters (0 = the generic kernel)
+int jbf_active_variant(const JbfLaunch& a)
+{
+    if (a.variant > 0) return a.variant;
+    if (a.variant < 0 && jbf_fast_supported(a)) return 1 + jbf_fast_default_variant(a);
+    return 0;
+}
+
 int launch_jbf(const JbfLaunch& a, hipStream_t s)
 {
     // variant -1: tuned kernel when one exists for this window and parameter regime, else the generic one

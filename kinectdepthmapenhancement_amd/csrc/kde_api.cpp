@@ -227,16 +227,28 @@ extern "C" int kde_jbf_destroy(kde_jbf* h)
     return KDE_OK;
 }
 
+static void jbf_fill_launch(const kde_jbf* h, JbfLaunch& a);
+
 static int jbf_filter(kde_jbf* h, int n, const float* depth, const uint8_t* guide, float* out, hipStream_t s)
 {
     JbfLaunch a;
-    a.width = h->width;
-    a.height = h->height;
+    jbf_fill_launch(h, a);
     a.n = n;
-    a.window = h->p.window_size;
     a.depth = depth;
     a.guide = guide;
     a.out = out;
+    return launch_jbf(a, s);
+}
+
+static void jbf_fill_launch(const kde_jbf* h, JbfLaunch& a)
+{
+    a.width = h->width;
+    a.height = h->height;
+    a.n = 0;
+    a.window = h->p.window_size;
+    a.depth = nullptr;
+    a.guide = nullptr;
+    a.out = nullptr;
     a.s_eff = h->s_eff.p;
     a.table_host = h->table.data();
     a.spatial_sigma = h->p.spatial_sigma;
@@ -247,7 +259,6 @@ static int jbf_filter(kde_jbf* h, int n, const float* depth, const uint8_t* guid
     a.cd_skip = h->cd_skip;
     a.d2_skip = h->d2_skip;
     a.variant = h->variant;
-    return launch_jbf(a, s);
 }
 
 static int jbf_presmooth(kde_jbf* h, int n, const uint8_t* bgr, uint8_t* dst, hipStream_t s)
@@ -352,6 +363,15 @@ extern "C" int kde_jbf_set_variant(kde_jbf* h, int variant)
     KDE_REQUIRE(h, "kde_jbf_set_variant: null handle");
     KDE_REQUIRE(variant >= -1 && variant < jbf_variant_count(), "kde_jbf_set_variant: variant %d out of range", variant);
     h->variant = variant;
+    return KDE_OK;
+}
+
+extern "C" int kde_jbf_active_variant(kde_jbf* h, int* variant)
+{
+    KDE_REQUIRE(h && variant, "kde_jbf_active_variant: null argument");
+    JbfLaunch a;
+    jbf_fill_launch(h, a);
+    *variant = jbf_active_variant(a);
     return KDE_OK;
 }
 
@@ -997,6 +1017,7 @@ struct kde_spdsr {
     DevBuf<kde_float3> edge_points;   // EdgeEnhanced3DPoints_Device            [max_batch][H][W]
     DevBuf<float> cluster_nd;         // ClusterND_Device (float4 per cluster)   [max_batch][rows*cols]
     DevBuf<double> sums, cov;         // per-cluster moments (replace the host cv::Mat / cv::PCA round trip)
+    int moments_dirty = 0;            // raised while sums / cov hold accumulated moments nobody has consumed (spdsr_kernels.hip)
     DevBuf<float> nxy;                // Projection_GPU::Normalized3D_Device (x, y of the unit-depth ray; the camera's)
     DevBuf<kde_float3> plane_fitted;  // Projection_GPU::PlaneFitted3D_Device    [max_batch][H][W]
     DevBuf<kde_float3> opt_a, opt_b;  // Projection_GPU::Optimized3D_Device, double-buffered (D5)
@@ -1043,6 +1064,7 @@ extern "C" int kde_spdsr_set_parameters(kde_spdsr* h, int rows, int cols, const 
     KDE_HIP_TRY(hipMemset(h->sums.p, 0, kb * 4 * sizeof(double)));
     KDE_HIP_TRY(hipMemset(h->cov.p, 0, kb * 6 * sizeof(double)));
     KDE_HIP_TRY(hipMemset(h->cluster_nd.p, 0, kb * 4 * sizeof(float)));
+    h->moments_dirty = 0;
     KDE_TRY(launch_spdsr_init_normalized(h->conv.cam, h->nxy.p, nullptr));
     KDE_HIP_TRY(hipStreamSynchronize(nullptr));
     return KDE_OK;
@@ -1058,8 +1080,8 @@ extern "C" int kde_spdsr_process_batch(kde_spdsr* h, int n, const float* depth_d
     KDE_TRY(kde_dimconv_projective_to_real_depth(&h->conv, n, h->p.ERS->refined_depth.p, h->edge_points.p, stream));
     // :65-170 on the device: per-cluster plane of the labelled cloud (no D2H / host PCA / H2D)
     hipStream_t s = as_stream(stream);
-    KDE_TRY(launch_spdsr_cluster_planes(h->p.width, h->p.height, n, h->nclusters, h->p.ERS->labels_a.p, h->edge_points.p,
-                                        h->sums.p, h->cov.p, h->cluster_nd.p, s));
+    KDE_TRY(launch_spdsr_cluster_planes(h->p.width, h->p.height, n, h->nclusters, h->p.max_batch, h->p.ERS->labels_a.p, h->edge_points.p,
+                                        h->sums.p, h->cov.p, h->cluster_nd.p, &h->moments_dirty, s));
     // Projector->PlaneProjection(ClusterND_Device, refined labels, EdgeEnhanced3DPoints_Device) (:190)
     h->n_last = n;
     return launch_spdsr_plane_projection(h->p.width, h->p.height, n, h->nclusters, h->cluster_nd.p, h->p.ERS->labels_a.p,

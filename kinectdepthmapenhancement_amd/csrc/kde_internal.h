@@ -133,6 +133,7 @@ struct JbfLaunch {
     int variant;
 };
 int launch_jbf(const JbfLaunch& a, hipStream_t s);
+int jbf_active_variant(const JbfLaunch& a);
 // tuned variants (jbf_fast.hip); variant ids there are 0-based, the public id is +1 (0 = generic kernel)
 int jbf_fast_variant_count();
 const char* jbf_fast_variant_name(int v);
@@ -209,8 +210,8 @@ int launch_ers_enhance(int width, int height, int n, const float* rd, const uint
                        float exp_zero, float* out, int variant, hipStream_t s);
 
 int launch_spdsr_init_normalized(const Camera& c, float* nxy, hipStream_t s);
-int launch_spdsr_cluster_planes(int width, int height, int n, int nclusters, const int32_t* labels, const kde_float3* pts,
-                                double* sums, double* cov, float* nd, hipStream_t s);
+int launch_spdsr_cluster_planes(int width, int height, int n, int nclusters, int table_frames, const int32_t* labels,
+                                const kde_float3* pts, double* sums, double* cov, float* nd, int* moments_dirty, hipStream_t s);
 int launch_spdsr_plane_projection(int width, int height, int n, int nclusters, const float* nd, const int32_t* labels,
                                   const kde_float3* pts, const float* nxy, kde_float3* plane_fitted, kde_float3* opt_a,
                                   kde_float3* opt_b, int sweeps, kde_float3** result, hipStream_t s);

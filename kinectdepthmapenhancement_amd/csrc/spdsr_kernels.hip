@@ -479,20 +479,31 @@ int launch_spdsr_init_normalized(const Camera& c, float* nxy, hipStream_t s)
 }
 
 // n frames back to back (labels, cloud; sums / cov / nd hold one table per frame)
-int launch_spdsr_cluster_planes(int width, int height, int n, int nclusters, const int32_t* labels, const kde_float3* pts,
-                                double* sums, double* cov, float* nd, hipStream_t s)
+int launch_spdsr_cluster_planes(int width, int height, int n, int nclusters, int table_frames, const int32_t* labels,
+                                const kde_float3* pts, double* sums, double* cov, float* nd, int* moments_dirty, hipStream_t s)
 {
     const int npix = width * height;
-    // sums / cov are zero on entry (cleared at creation and by cluster_planes_kernel after every use)
+    // sums / cov are zero on entry: cleared at creation and by cluster_planes_kernel after every use.  *moments_dirty (a host
+    // flag of the handle) is raised before the moments are accumulated and lowered once the kernel that consumes and clears
+    // them has been enqueued: a call that finds it raised -- an earlier call failed between the two -- clears the tables
+    // itself, so a failed launch cannot make every later Process on the handle return wrong planes.
+    if (*moments_dirty) {
+        KDE_HIP_TRY(hipMemsetAsync(sums, 0, (size_t)table_frames * nclusters * 4 * sizeof(double), s));
+        KDE_HIP_TRY(hipMemsetAsync(cov, 0, (size_t)table_frames * nclusters * 6 * sizeof(double), s));
+    }
+    *moments_dirty = 1;
     const int use_lds = nclusters <= kMaxLdsClusters;
     const int blocks = ceil_div(npix, kThreads * 8);
     hipLaunchKernelGGL(cluster_moments_kernel<false>, dim3(blocks, n), dim3(kThreads), use_lds ? (size_t)nclusters * 4 * 8 : 0, s,
                        npix, nclusters, use_lds, labels, pts, sums, cov);
+    KDE_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(cluster_moments_kernel<true>, dim3(blocks, n), dim3(kThreads), use_lds ? (size_t)nclusters * 6 * 8 : 0, s,
                        npix, nclusters, use_lds, labels, pts, sums, cov);
+    KDE_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(cluster_planes_kernel, dim3(ceil_div(nclusters, 64), n), dim3(64), 0, s, nclusters, sums, cov,
                        reinterpret_cast<float4*>(nd));
     KDE_HIP_TRY(hipGetLastError());
+    *moments_dirty = 0;
     return KDE_OK;
 }
 

@@ -149,6 +149,12 @@ class JointBilateralFilter(_Handle):
     def set_variant(self, v: int) -> None:
         check(lib().kde_jbf_set_variant(self._h, v))
 
+    def active_variant(self) -> str:
+        """name of the kernel this handle's parameters and variant setting select ("generic-32x8-1px" when no tuned one applies)"""
+        v = C.c_int(-1)
+        check(lib().kde_jbf_active_variant(self._h, C.byref(v)))
+        return lib().kde_jbf_variant_name(v.value).decode()
+
     @staticmethod
     def variants():
         n = lib().kde_jbf_variant_count()

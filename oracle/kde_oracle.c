@@ -171,6 +171,20 @@ static const double kUnder = 0x1p-150;              /* a float32 product at or b
 
 static const double kUnit = 0x1p-149;               /* the float32 denormal grid */
 
+/* Half-widths of the two decision bands ("is this tap ON a Q1 decision?"), relative.
+ *  - ENVELOPE mode (round 2: the average is NOT given, okde_env): the band also has to absorb what the uncertainty of the
+ *    average does to a tap at the threshold, see thr_band(); 1.5e-4 / 5e-4 as before.
+ *  - STAGE mode (the average IS given, okde_*_stage): only the decision arithmetic itself is left.  In x = (d - avg)^2 / dden
+ *    the float32 forms differ from binary64 by the rounding of (d - avg), of its square / the scaled t = (d - avg) sd, of
+ *    sd and of the threshold (t_skip^2 resp. the host's exact d2_skip): <= ~8 roundings of 2^-24 = 5e-7 (the tuned kernels'
+ *    t^2 < T^2 form; the generic kernel compares the float32 square with the exact float32 threshold, 2e-7).  2e-6 is four
+ *    times that.  A whole weight S cf df is formed in the log2 domain from an argument of magnitude <= 150 (ulp 2^-17 = 7.6e-6,
+ *    two or three roundings) and one v_exp_f32 (1 ulp): <= 2e-5 relative; 5e-5 around the underflow-to-zero point 2^-150.
+ *    (the 1.5e-4 / 5e-4 of the envelope were used here too and put ~6 x more pixels into the interval class than
+ *    the arithmetic warrants: config 2 BAND 239 -> 39.) */
+static const double kDecisionBandEnv = 1.5e-4, kWeightBandEnv = 5e-4;
+static const double kDecisionBandStage = 2e-6, kWeightBandStage = 5e-5;
+
 /* quantisation allowance: the float32 code holds a weight below 2^-126 on the 2^-149 grid (expf rounds to it, and so
  * does every product), so two faithful float32 evaluations with different expf implementations differ by a grid unit or
  * two per weight.  q = +-1 moves every weight by 2 units in the direction that raises / lowers the weighted mean around
@@ -189,7 +203,7 @@ static inline double quantised(double f, double d, double centre, int q)
  * everything an evaluation whose average lies in between can return just before the decision flips. */
 static inline double thr_band(double band_eps, double wa, double dden)
 {
-    return 1.5e-4 + (dden > 0.0 ? 2.0 * band_eps * fabs(wa) / sqrt(kXZ * dden) : 0.0);
+    return kDecisionBandEnv + (dden > 0.0 ? 2.0 * band_eps * fabs(wa) / sqrt(kXZ * dden) : 0.0);
 }
 
 /* Number of additions that can round when n weights are summed in float32: the taps whose weight is at least half
@@ -223,10 +237,11 @@ static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double av
                          double* den_out, double band_eps, double* tol_out, const double* avg_abs, double* wout)
 {
     const double U = kUnder * und_scale;
+    const double wband = avg_abs ? kWeightBandStage : kWeightBandEnv;
     double wa = 0.0, wt = 0.0;
     for (int k = 0; k < t->n; k++) {
         double f = t->base[k];
-        if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
+        if (fabs(f / kUnder - 1.0) <= wband) *band |= 1;
         if (f <= U) f = 0.0;
         else f = quantised(f, t->d[k], centre1, q1);
         wa += t->d[k] * f;
@@ -235,7 +250,7 @@ static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double av
     if (den_out) den_out[0] = wt, den_out[1] = 0.0;
     if (!avg_abs && !(wt > 0.0)) return 0.0;      /* (with a GIVEN average pass 2 does not depend on pass 1's sums) */
     if (n_eff) *n_eff = n_significant(t->base, NULL, t->n, wt, U);
-    const double tol = (depth_on && !avg_abs) ? thr_band(band_eps, wa / wt, dden) : 1.5e-4;
+    const double tol = avg_abs ? kDecisionBandStage : (depth_on ? thr_band(band_eps, wa / wt, dden) : kDecisionBandEnv);
     if (tol_out) *tol_out = tol;
     wa = avg_abs ? *avg_abs : wa / wt * (1.0 + avg_rel);      /* avg_abs: the stage-wise check evaluates pass 2 at a GIVEN average */
     double nu = 0.0, de = 0.0;
@@ -253,7 +268,7 @@ static double jbf_eval64(const jbf_taps* t, double dden, int depth_on, double av
             int keep = xd < kXZ * thr_scale;
             if (is_open && g_force && g_force[k] >= 0) keep = !g_force[k];
             if (keep) f *= exp(-xd);
-            if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
+            if (fabs(f / kUnder - 1.0) <= wband) *band |= 1;
             if (wout) wout[k] = f;
             if (f <= U) continue;
         }
@@ -371,7 +386,7 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                     }
                 int band = 0;
                 double n_eff = 1.0, dens[2] = {0.0, 0.0};
-                double tol = 1.5e-4;
+                double tol = kDecisionBandEnv;
                 const double r0 = jbf_eval64(&t, dden, depth_sigma != 0.0f, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL, NULL, NULL);
                 /* rounding of the float32 sums behind the average: the first-order bound of recursive summation over
                  * the taps that can round at all (see n_significant), plus the products and the division */
@@ -386,7 +401,7 @@ void okde_jbf_kernel(int width, int height, const float* depth, const uint8_t* g
                             for (int c = -1; c <= 1; c++) {
                                 int dummy = 0;
                                 env_add(&e, jbf_eval64(&t, dden, depth_sigma != 0.0f, a * eps_avg, 1.0 + b * tol,
-                                                       1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, NULL, NULL));
+                                                       1.0 + c * kWeightBandEnv, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, NULL, NULL));
                             }
                 }
                 /* a sum of weights so small that the 2^-149 grid is within 1e-6 of it: the float32 value is
@@ -582,7 +597,7 @@ void okde_jbf_stage(int width, int height, const float* depth, const uint8_t* gu
             double wa = 0.0, wt = 0.0;
             for (int k = 0; k < t.n; k++) {
                 const double f = t.base[k];
-                if (fabs(f / kUnder - 1.0) <= 5e-4) band1 = 1;
+                if (fabs(f / kUnder - 1.0) <= kWeightBandStage) band1 = 1;
                 if (f <= kUnder) continue;
                 wa += t.d[k] * f;
                 wt += f;
@@ -615,7 +630,7 @@ void okde_jbf_stage(int width, int height, const float* depth, const uint8_t* gu
                 /* ---- pass 2 in binary64 at the given average ---- */
                 const double a = (double)a32;
                 int band2 = 0;
-                double dens[2] = {0.0, 0.0}, tol = 1.5e-4;
+                double dens[2] = {0.0, 0.0}, tol = kDecisionBandStage;
                 double w2[OKDE_MAXTAPS];
                 fin = jbf_eval64(&t, dden, don, 0.0, 1.0, 1.0, &band2, NULL, 0, 0.0, 0, 0.0, dens, 0.0, &tol, &a, w2);
                 env_add(&e, fin);
@@ -624,7 +639,7 @@ void okde_jbf_stage(int width, int height, const float* depth, const uint8_t* gu
                     for (int b = -1; b <= 1; b++)
                         for (int c = -1; c <= 1; c++) {
                             int dummy = 0;
-                            env_add(&e, jbf_eval64(&t, dden, don, 0.0, 1.0 + b * tol, 1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0,
+                            env_add(&e, jbf_eval64(&t, dden, don, 0.0, 1.0 + b * tol, 1.0 + c * kWeightBandStage, &dummy, NULL, 0, 0.0, 0,
                                                    0.0, NULL, 0.0, NULL, &a, NULL));
                         }
                     /* mixed decisions: every open tap above the result "skipped" (full weight) and every one below it
@@ -1228,6 +1243,7 @@ static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, i
                          double centre2, double* den_out, double band_eps, double* tol_out, const double* avg_abs, double* wout)
 {
     const double U = kUnder * und_scale;
+    const double wband = avg_abs ? kWeightBandStage : kWeightBandEnv;      /* see jbf_eval64 */
     double wa = 0.0, wt = 0.0;
     double w1[OKDE_MAXTAPS];
     for (int k = 0; k < t->n; k++) {
@@ -1236,7 +1252,7 @@ static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, i
         double f = t->s[k];
         if (color_sigma_in != 0.0f && expf(-t->cd[k] / (2 * (color_sigma_in * color_sigma_in))) != 0.0f)
             f *= exp(-(double)t->cd[k] / (2.0 * (double)color_sigma_in * (double)color_sigma_in));
-        if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
+        if (fabs(f / kUnder - 1.0) <= wband) *band |= 1;
         if (f <= U) f = 0.0;
         else f = quantised(f, t->d[k], centre1, q1);
         w1[k] = f;
@@ -1246,7 +1262,7 @@ static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, i
     if (den_out) den_out[0] = wt, den_out[1] = 0.0;
     if (!avg_abs && !(wt > 0.0)) return 0.0;
     if (n_eff) *n_eff = n_significant(w1, NULL, t->n, wt, 0.0);
-    const double tol = (depth_on && !avg_abs) ? thr_band(band_eps, wa / wt, dden) : 1.5e-4;     /* see jbf_eval64 */
+    const double tol = avg_abs ? kDecisionBandStage : (depth_on ? thr_band(band_eps, wa / wt, dden) : kDecisionBandEnv);
     if (tol_out) *tol_out = tol;
     wa = avg_abs ? *avg_abs : wa / wt * (1.0 + avg_rel);      /* avg_abs: see jbf_eval64 */
     float cs = color_sigma_in;
@@ -1271,7 +1287,7 @@ static double ers_eval64(const ers_taps* t, float color_sigma_in, double dden, i
             if (is_open && g_force && g_force[k] >= 0) keep = !g_force[k];      /* see jbf_eval64 */
             if (keep) f *= exp(-xd);
         }
-        if (fabs(f / kUnder - 1.0) <= 5e-4) *band |= 1;
+        if (fabs(f / kUnder - 1.0) <= wband) *band |= 1;
         if (wout) wout[k] = f;
         if (f <= U) continue;            /* NaN fails the test and is summed in, as in float32 */
         if (f == f) f = quantised(f, t->d[k], centre2, q2);
@@ -1406,7 +1422,7 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                 }
                 int band = 0;
                 double n_eff = 1.0, dens[2] = {0.0, 0.0};
-                double tol = 1.5e-4;
+                double tol = kDecisionBandEnv;
                 const double r0 = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band, &n_eff, 0, 0.0, 0, 0.0, dens, 0.0, NULL, NULL, NULL);
                 const double eps_avg = (4.0 + 0.5 * n_eff) * 1.1920928955078125e-7;     /* as in okde_jbf_kernel */
                 for (int v = 0; v < nalt; v++)
@@ -1423,7 +1439,7 @@ void okde_ers_enhance(int width, int height, const float* rd, const uint8_t* bgr
                                 for (int c = -1; c <= 1; c++) {
                                     int dummy = 0;
                                     const double r = ers_eval64(&t, color_sigma_in, dden, don, alt[v], a * eps_avg,
-                                                                1.0 + b * tol, 1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, NULL, NULL);
+                                                                1.0 + b * tol, 1.0 + c * kWeightBandEnv, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, NULL, NULL);
                                     if (r != r) nan_ok = 1;
                                     else env_add(&e, r);
                                 }
@@ -1545,7 +1561,7 @@ void okde_ers_stage(int width, int height, const float* rd, const uint8_t* bgr, 
                 double f = t.s[k];
                 if (color_sigma_in != 0.0f && expf(-t.cd[k] / (2 * (color_sigma_in * color_sigma_in))) != 0.0f)
                     f *= exp(-(double)t.cd[k] / cden);
-                if (fabs(f / kUnder - 1.0) <= 5e-4) band1 = 1;
+                if (fabs(f / kUnder - 1.0) <= kWeightBandStage) band1 = 1;
                 if (f > kTinyW && f <= kUnder) sub1 = 1;
                 if (f <= kUnder) continue;
                 w1[k] = f;
@@ -1591,7 +1607,7 @@ void okde_ers_stage(int width, int height, const float* rd, const uint8_t* bgr, 
                 /* ---- pass 3 in binary64 from (average, deviation) as given; .cu:171 forms the adaptive sigma so: ---- */
                 const float adaptive = (float)(5.0 * (double)dev32 / (double)(a32 * a32));
                 int band3 = 0;
-                double dens[2] = {0.0, 0.0}, tol = 1.5e-4;
+                double dens[2] = {0.0, 0.0}, tol = kDecisionBandStage;
                 double w3[OKDE_MAXTAPS];
                 for (int k = 0; k < t.n; k++) w3[k] = 0.0;
                 fin = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0, 1.0, &band3, NULL, 0, 0.0, 0, 0.0, dens,
@@ -1604,7 +1620,7 @@ void okde_ers_stage(int width, int height, const float* rd, const uint8_t* bgr, 
                         for (int c = -1; c <= 1; c++) {
                             int dummy = 0;
                             const double r = ers_eval64(&t, color_sigma_in, dden, don, adaptive, 0.0, 1.0 + b * tol,
-                                                        1.0 + c * 5e-4, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, &a, NULL);
+                                                        1.0 + c * kWeightBandStage, &dummy, NULL, 0, 0.0, 0, 0.0, NULL, 0.0, NULL, &a, NULL);
                             if (r != r) nan_seen = 1;
                             else env_add(&e, r);
                         }

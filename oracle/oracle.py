@@ -235,9 +235,14 @@ def stage_check(final, st: Stage, rtol=1e-4):
         width = np.where(band & (st.hi > 0), (st.hi - st.lo) / np.maximum(np.abs(st.fin64), 1e-300), 0.0)
     bad = mismatch | bad_avg | bad_dev | bad_nan | bad_zero | bad_rel | bad_band
     nb = int(band.sum())
+    grid = (fl & Stage.GRID) != 0
+    ndec = int((band & ~grid).sum())            # interval-checked because a tap is ON a decision (not the denormal-grid class)
+    expect_avg = have_avg & ~band & ~mismatch   # every strict pixel that has an average must have had it compared
     q = lambda a, m, pc: float(np.percentile(a[m], pc)) if m.any() else 0.0
-    return {"bad": bad, "rel": rel, "n": int(got.size), "band": nb, "grid": int(((fl & Stage.GRID) != 0).sum()),
-            "band_frac": nb / max(1, got.size), "mismatch": int(mismatch.sum()),
+    return {"bad": bad, "rel": rel, "n": int(got.size), "band": nb, "grid": int(grid.sum()), "band_decision": ndec,
+            "band_frac": nb / max(1, got.size), "band_decision_frac": ndec / max(1, got.size), "grid_frac": int(grid.sum()) / max(1, got.size),
+            "avg_checked_of_strict": float((cmp_avg & expect_avg).sum() / max(1, int(expect_avg.sum()))),
+            "mismatch": int(mismatch.sum()),
             "bad_avg": int(bad_avg.sum()), "bad_dev": int(bad_dev.sum()), "bad_nan": int(bad_nan.sum()),
             "bad_zero": int(bad_zero.sum()), "bad_rel": int(bad_rel.sum()), "outside_band": int(bad_band.sum()),
             "max_rel_strict": float(rel[strict].max()) if strict.any() else 0.0,

@@ -102,8 +102,8 @@ def assert_depth_close(got, ref, rtol=1e-4, ill=None, max_bad=0, what="depth", m
     return r["max_rel_unflagged"]
 
 
-def _stage_report(r, what, band_max, ignore=None):
-    PARITY_LOG.append(f"{what} [stage-wise]: {r['n']} px, BAND {r['band']} ({r['band_frac']:.2e}, grid {r['grid']}; width p50 "
+def _stage_report(r, what, band_max, ignore=None, decision_max=None):
+    PARITY_LOG.append(f"{what} [stage-wise]: {r['n']} px, BAND {r['band']} ({r['band_frac']:.2e}: decision {r['band_decision']} = {r['band_decision_frac']:.2e}, grid {r['grid']}; width p50 "
                       f"{r['band_width_p50']:.1e} p99 {r['band_width_p99']:.1e} max {r['band_width_max']:.1e}), strict max rel "
                       f"{r['max_rel_strict']:.2e}, average within {r['avg_bound_frac_max']:.2f} of its bound "
                       f"(bound p50 {r['avg_tol_p50']:.1e} max {r['avg_tol_max']:.1e}), deviation within {r['dev_bound_frac_max']:.2f}")
@@ -115,9 +115,14 @@ def _stage_report(r, what, band_max, ignore=None):
                              f"{r['bad_nan']}, zero-mask {r['bad_zero']}, rel {r['bad_rel']} max {r['max_rel_strict']:.3e}, outside "
                              f"band interval {r['outside_band']}, mismatch {r['mismatch']}); first: {idx}")
     assert r["band_frac"] <= band_max, f"{what}: {r['band_frac']:.3e} of the pixels are BAND (> {band_max})"
+    if decision_max is not None:
+        assert r["band_decision_frac"] <= decision_max, \
+            f"{what}: {r['band_decision_frac']:.3e} of the pixels are interval-checked for a tap on a decision (> {decision_max})"
+    # every strict pixel that has a first-pass average had it compared with binary64 (no silent exclusion)
+    assert r["avg_checked_of_strict"] >= 0.9999, f"{what}: only {r['avg_checked_of_strict']:.4f} of the strict pixels' averages were checked"
 
 
-def assert_k1_stagewise(params, depth, guide, got, variant=-1, what="K1", band_max=0.05, rtol=1e-4, ignore=None):
+def assert_k1_stagewise(params, depth, guide, got, variant=-1, what="K1", band_max=0.02, rtol=1e-4, ignore=None, decision_max=None):
     """The K1 bar (round 3).  `got` is the PRODUCT library's output for (depth, guide, params, variant), [H,W]:
       1. the same call on tools/hooks/libkde_hip_stage.so (same sources + dumps) must reproduce `got` to the bit, so the
          first-pass average it dumps is the one the product kernel used;
@@ -139,12 +144,12 @@ def assert_k1_stagewise(params, depth, guide, got, variant=-1, what="K1", band_m
     assert same, f"{what}: the stage build's output differs from the product library's"
     st = O.jbf_stage(depth, guide, p.window_size, p.spatial_sigma, p.color_sigma, p.depth_sigma, avg_in=avg[0])
     r = O.stage_check(got, st, rtol)
-    _stage_report(r, what, band_max, ignore)
+    _stage_report(r, what, band_max, ignore, decision_max)
     return r
 
 
-def assert_k10_stagewise(color_labels, depth_labels, depth, bgr, got, variant=0, what="K10", band_max=0.05, rtol=1e-4,
-                         ignore=None):
+def assert_k10_stagewise(color_labels, depth_labels, depth, bgr, got, variant=0, what="K10", band_max=0.02, rtol=1e-4,
+                         ignore=None, decision_max=None):
     """The K10 bar (round 3), as assert_k1_stagewise: EdgeRefinedSuperpixel::EdgeRefining is re-run on the stage build
     (final depth bit-identical to `got`), which dumps the label-restricted average and the mean absolute deviation per
     pixel; both are checked against binary64, and the last pass is evaluated in binary64 from them."""
@@ -155,7 +160,7 @@ def assert_k10_stagewise(color_labels, depth_labels, depth, bgr, got, variant=0,
     assert eq, f"{what}: the stage build's output differs from the product library's"
     st = O.ers_stage(s["edge_depth"], bgr, s["labels"], avg_in=s["avg"], dev_in=s["dev"])
     r = O.stage_check(got, st, rtol)
-    _stage_report(r, what, band_max, ignore)
+    _stage_report(r, what, band_max, ignore, decision_max)
     return r
 
 

@@ -36,10 +36,15 @@ def test_k1_stage_flags_band_pixels_and_brackets_both_outcomes(oracle):
     st0 = oracle.jbf_stage(depth, bgr, 5, 70.0, 50.0, 20.0)
     assert not st0.band.any()
     avg = float(st0.avg32[4, 4])
-    depth[4, 5] = np.float32(avg + 288.4100)                           # inside the 1.5e-4 band around sqrt(150 ln2 * 800)
+    thr = float(np.sqrt(150.0 * np.log(2.0) * 800.0))                  # 288.4053...: (d - avg)^2 / (2 sigma_d^2) == 150 ln 2
+    depth[4, 5] = np.float32(avg + thr)                                # the nearest float: inside the 2e-6 band (stage mode) in x
     st = oracle.jbf_stage(depth, bgr, 5, 70.0, 50.0, 20.0, avg_in=np.full((h, w), avg, np.float32))
     assert st.band[4, 4]
     assert st.hi[4, 4] > st.lo[4, 4] * 1.001                            # skipped vs kept differ by about 288 / 25
+    near = depth.copy()
+    near[4, 5] = np.float32(avg + thr * (1.0 + 1e-5))                   # 2e-5 in x beyond the point: r03's 1.5e-4 band held it, this one does not
+    st1 = oracle.jbf_stage(near, bgr, 5, 70.0, 50.0, 20.0, avg_in=np.full((h, w), avg, np.float32))
+    assert not st1.band[4, 4] and abs(st1.fin64[4, 4] - st.hi[4, 4]) < 0.5      # decided: skipped (full weight)
     far = depth.copy()
     far[4, 5] = np.float32(avg + 295.0)                                 # clearly beyond: skipped, no band
     st2 = oracle.jbf_stage(far, bgr, 5, 70.0, 50.0, 20.0, avg_in=np.full((h, w), avg, np.float32))
@@ -148,9 +153,11 @@ def test_k1_stage_open_decisions_on_both_sides_of_the_mean(oracle):
     """tools/stress_parity.py seed 501 case 38542 (crop: tests/golden/k1_mixed_open_decisions.npz; window 31, sigma_s 0.5, colour
     term off, sigma_d 70).  The spatial table underflows beyond r^2 = 52, so far taps enter with weight 1 (Q1) and the average
     (2489 mm) sits between a near surface (1435 mm) and a far one (3500 mm), 1009.4 mm = the depth-factor underflow distance
-    from BOTH: one tap at 1479.95 mm lies 5e-9 (relative, in x) beyond the underflow point and one at 3498.83 mm 8e-5 beyond.
-    The float32 code skips the first (full weight) and keeps the second; taking the open decisions of all taps the same way
-    brackets [2133.30, 2135.16] and misses its value 2136.88 — the extremes are the MIXED decisions."""
+    from BOTH: one tap at 1479.95 mm lies 5e-9 (relative, in x) from the underflow point and one at 3498.83 mm 7.8e-5 beyond it.
+    Under r03's 1.5e-4 decision band both were open and the float32 value (2136.88: near tap multiplied in, far tap skipped)
+    lay outside the all-or-nothing interval [2133.30, 2135.16] -- the extremes are the MIXED decisions, which is why the
+    interval is formed per tap.  Under the 2e-6 band of r04 only the near tap is open: the far one is decided (skipped, as the
+    float32 code does) and the interval shrinks to the two outcomes of ONE tap."""
     import os
     from conftest import GOLDEN
     z = np.load(os.path.join(GOLDEN, "k1_mixed_open_decisions.npz"))
@@ -161,14 +168,38 @@ def test_k1_stage_open_decisions_on_both_sides_of_the_mean(oracle):
     # (only the crop's centre pixel has its whole window inside the crop; there the HIP kernel had returned the same bits)
     assert abs(float(out[y, x]) - 2136.8796) < 1e-3 and out[y, x] == z["got"][y, x]
     assert st.flags[y, x] & oracle.Stage.BAND
-    assert st.lo[y, x] < 2133.4 and st.hi[y, x] > 2136.87 and st.hi[y, x] - st.lo[y, x] < 6.0
-    assert 2135.0 < st.fin64[y, x] < 2135.3               # the arithmetic's own decisions at this average: one tap differs
+    assert 2135.0 < st.lo[y, x] < 2135.3 and 2136.87 < st.hi[y, x] < 2136.89     # near tap skipped / multiplied in; far tap decided
+    assert 2135.0 < st.fin64[y, x] < 2135.3               # binary64's own decision for the tap 5e-9 from the point
     assert not oracle.stage_check(out, st)["bad"].any()
-    # the bracket is not a blank cheque: a value one more tap away on either side is still rejected
-    for delta in (+2.0, -7.5):
+    # the bracket is not a blank cheque: a value one more tap away on either side is rejected -- including 2133.3, which
+    # r03's band admitted
+    for delta in (+2.0, -3.5, -7.5):
         bad = out.copy()
         bad[y, x] += np.float32(delta)
         assert oracle.stage_check(bad, st)["bad"][y, x]
+
+
+def test_k1_stage_mixed_open_decisions_bracket(oracle):
+    """two taps ON the depth-factor underflow distance (to the nearest float: within 2e-6 in x), one above and one below the
+    given average: the admissible values are those of all four decision combinations, and the extremes are the MIXED ones
+    (upper tap skipped = full weight with lower tap multiplied in = weight ~ 0, and the reverse), not all-or-nothing."""
+    h, w = 9, 9
+    depth = np.full((h, w), 2000.0, np.float32)
+    bgr = np.full((h, w, 3), 50, np.uint8)
+    thr = float(np.sqrt(150.0 * np.log(2.0) * 2.0 * 70.0 * 70.0))      # 1009.4 mm at sigma_d 70
+    avg = 2000.0
+    depth[4, 5] = np.float32(avg + thr)
+    depth[4, 3] = np.float32(avg - thr)
+    st = oracle.jbf_stage(depth, bgr, 5, 70.0, 50.0, 70.0, avg_in=np.full((h, w), avg, np.float32))
+    assert st.flags[4, 4] & oracle.Stage.BAND
+    # 23 taps at 2000 with weight ~1 each, the two open taps with weight ~1 (skipped) or ~1e-45 (multiplied in)
+    up_only, down_only = (23 * 2000.0 + depth[4, 5]) / 24.0, (23 * 2000.0 + depth[4, 3]) / 24.0
+    assert st.hi[4, 4] > up_only - 0.5 and st.lo[4, 4] < down_only + 0.5
+    assert abs(st.hi[4, 4] - up_only) < 1.0 and abs(st.lo[4, 4] - down_only) < 1.0      # spatial weights 0.9992 .. 1
+    for v, ok in ((up_only, True), (down_only, True), (2000.0, True), (up_only + 3.0, False), (down_only - 3.0, False)):
+        got = np.full((h, w), 2000.0, np.float32)
+        got[4, 4] = np.float32(v)
+        assert oracle.stage_check(got, st)["bad"][4, 4] == (not ok), v
 
 
 def test_k1_stage_pass2_weights_below_the_underflow_point_that_survive(oracle):

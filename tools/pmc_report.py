@@ -11,9 +11,17 @@ launches of one (kernel name, grid size); derived figures follow /opt/skills/gui
                         gfx950 for wide coalesced reads; the factor is calibrated in the same run on the library's float4
                         copy kernel (reads exactly what it writes) and reported as `fetch_correction_measured`.
   cycles              = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs)
-  valu_busy           = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles)        (quad-cycles -> cycles)
-  valu_slot_frac      = (SQ_INSTS_VALU + SQ_INSTS_VALU_TRANS_F32) x 4 / (1024 x cycles): issue slots of 4 cycles, a
-                        transcendental counts two (the model bench.py's roofline.valu uses)
+  valu_busy           = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles).  NOT a fraction of a ceiling: the counter books one
+                        quad-cycle per VALU instruction (two per transcendental), but gfx950 issues v_mul / v_add / v_fma_f32 /
+                        v_mov / v_and ... in TWO cycles, so plain-f32 kernels read above 1 (r03: 1.06-1.29).  Kept for comparison.
+  valu_slot_frac      = (SQ_INSTS_VALU + SQ_INSTS_VALU_TRANS_F32) x 4 / (1024 x cycles): the same 4-cycle model from counts
+  mix (r04)           = the kernel's VALU instruction mix priced with the MEASURED issue cost of every opcode
+                        (tools/valu_mix.py, profiles/valu_costs.json from tools/valu_microbench):
+                          bare_stream_ns   = sum_m n_m x cost_ns(m) per wave x SQ_WAVES / 1024 SIMDs  -- what the VALU instructions
+                                             alone would take with every SIMD issuing back to back
+                          valu_cycles_frac = bare_stream_ns / duration_ns (duration = End - Start timestamp of the profiled launch)
+                        <= 1 by construction: the costs are the cheapest each opcode gets at any occupancy.  This is the
+                        "fraction of the VALU-issue ceiling" DESIGN.md quotes per kernel.
   waves_per_simd      = SQ_WAVE_CYCLES x 4 / (1024 x cycles)                    (mean resident waves per SIMD)
   lds_conflict_frac   = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 `--algo` optionally maps a kernel-name substring to algorithmic bytes per launch so that traffic ratios are in the file."""
@@ -28,6 +36,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def _code_only(text):
@@ -84,7 +93,13 @@ def main():
     keep = re.compile(a.keep)
     algo = json.load(open(a.algo)) if a.algo else {}
 
-    table = defaultdict(lambda: {"counters": defaultdict(list), "meta": {}})
+    table = defaultdict(lambda: {"counters": defaultdict(list), "meta": {}, "dur": []})
+    try:
+        import valu_mix
+        costs, kern_asm = valu_mix.load_costs(), valu_mix.all_kernels()
+    except Exception as ex:                     # no cost table / no compiler: the table is written without the mix
+        print(f"pmc_report: no instruction-mix pricing ({type(ex).__name__}: {ex})", file=sys.stderr)
+        costs, kern_asm = None, {}
     for path in glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
@@ -94,6 +109,8 @@ def main():
                 key = (short(name), int(row["Grid_Size"]))
                 e = table[key]
                 e["counters"][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                if row.get("End_Timestamp") and row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    e["dur"].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
                 e["meta"] = {"workgroup": int(row.get("Workgroup_Size", 0) or 0), "lds_bytes": int(row.get("LDS_Block_Size", 0) or 0),
                              "vgprs": int(row.get("VGPR_Count", 0) or 0), "sgprs": int(row.get("SGPR_Count", 0) or 0)}
 
@@ -128,6 +145,14 @@ def main():
                 d["waves_per_simd"] = c["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * cyc)
             if "SQ_ACTIVE_INST_LDS" in c:
                 d["lds_inst_busy"] = c["SQ_ACTIVE_INST_LDS"] * 4.0 / (1024.0 * cyc)
+        if e["dur"]:
+            d["duration_ns"] = sum(e["dur"]) / len(e["dur"])
+        mix = None
+        if costs and name in kern_asm and c.get("SQ_WAVES") and "SQ_INSTS_VALU" in c:
+            mix = valu_mix.estimate(kern_asm[name], costs, c["SQ_INSTS_VALU"] / c["SQ_WAVES"], c.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / c["SQ_WAVES"])
+            mix["bare_stream_ns"] = mix["bare_ns_per_wave"] * c["SQ_WAVES"] / 1024.0
+            if d.get("duration_ns"):
+                d["valu_cycles_frac"] = mix["bare_stream_ns"] / d["duration_ns"]
         if c.get("SQ_LDS_IDX_ACTIVE"):
             d["lds_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
         for sub, nbytes in algo.items():
@@ -139,7 +164,8 @@ def main():
         out["kernels"].append({"kernel": name, "grid": grid, **e["meta"],
                                "launches": max(len(v) for v in e["counters"].values()),
                                "counters": {k: round(v, 2) for k, v in sorted(c.items())},
-                               "derived": {k: (round(v, 5) if abs(v) < 100 else round(v, 1)) for k, v in d.items()}})
+                               "derived": {k: (round(v, 5) if abs(v) < 100 else round(v, 1)) for k, v in d.items()},
+                               **({"mix": mix} if mix else {})})
     out["fetch_correction_measured"] = corr
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1)

@@ -12,7 +12,9 @@
 #   bench       the plain bench line
 #   chain       tools/bench_chain.py at 1080p and 640x480, tools/bench_spdsr.py, tools/bench_mrf.py
 #   sweep       K1 variant / tile sweeps (BASELINE config 3)
-#   micro       tools/valu_microbench (VALU issue costs)
+#   micro       tools/valu_microbench (VALU issue costs) -> valu_costs.json (tools/valu_costs.py)
+#   micro_pmc   the SQ_INSTS_VALU_* class counters over the micro-benchmark (which counter books which opcode)
+#   windows     every tuned K1 window next to the generic kernel
 #   shard       the C++ sharding host (examples/shard_replay, RCCL broadcast) against bench.py on IDENTICAL frames
 #               (bench.py --dump-frames -> shard_replay --frames-file): the two N = 1 figures must agree
 # PMC passes hold one counter group each and no tracing domain (MI355X_MICROARCH.md, rocprofv3 PMC slots).
@@ -156,7 +158,23 @@ PY
   ;;
 micro)
   tools/valu_microbench > "$OUT/valu_microbench.txt" 2>&1
-  cat "$OUT/valu_microbench.txt"
+  python3 tools/valu_costs.py "$OUT/valu_microbench.txt" > "$OUT/valu_costs.json"
+  python3 tools/valu_costs.py "$OUT/valu_microbench.txt" --table
+  ;;
+micro_pmc)
+  # which SQ_INSTS_VALU_* class counter books which opcode (one kernel of the micro-benchmark = one opcode)
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_WAVES \
+      --output-format csv -d "$OUT/micro_pmc/a" -o a -- tools/valu_microbench > "$OUT/micro_pmc_a.log" 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_VALU SQ_WAVES \
+      --output-format csv -d "$OUT/micro_pmc/b" -o b -- tools/valu_microbench > "$OUT/micro_pmc_b.log" 2>&1
+  find "$OUT/micro_pmc" -name "*.csv" ! -name "*counter_collection.csv" -delete
+  ;;
+windows)
+  # every tuned window next to the generic kernel (one pixel per thread): tools/sweep_jbf.py, 64 x 640x480
+  for W in 3 5 7 9 11 13 15 17 19 21; do
+    python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window $W --with-generic --iters 3 --rounds 3
+  done > "$OUT/sweep_k1_windows.log" 2> "$OUT/sweep_windows.err"
+  cat "$OUT/sweep_k1_windows.log"
   ;;
 *) echo "unknown step $STEP"; exit 2 ;;
 esac

@@ -90,6 +90,7 @@ constexpr int kUnroll = 32;    // instructions (or instruction groups) per loop 
     X(CVT_F32_I32, "v_cvt_f32_i32", 1, asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(a[i]) : "v"(u[i]));)                          \
     X(CVT_UBYTE, "v_cvt_f32_ubyte1", 1, asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(a[i]) : "v"(u[i]));)                      \
     X(CVT_PK_U8, "v_cvt_pk_u8_f32", 1, asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(u[i]) : "v"(a[i]));)                 \
+    X(CNDMASK_VCC, "v_cndmask_b32", 1, asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c0));)                   \
     X(CNDMASK_SGPR, "v_cndmask_b32_e64", 1, asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a[i]) : "v"(c0));)      \
     X(CMP_E32, "v_cmp_lt_f32_e32", 1, asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(c0) : "vcc");)             \
     X(CMP_E64, "v_cmp_ge_f32_e64", 1, asm volatile("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m64) : "v"(a[i]), "v"(c0));)             \
@@ -106,6 +107,20 @@ constexpr int kUnroll = 32;    // instructions (or instruction groups) per loop 
     X(DIV_SCALE, "v_div_scale_f32", 1, asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(a[i]) : "v"(c0) : "vcc");)      \
     X(DIV_FMAS, "v_div_fmas_f32", 1, asm volatile("v_div_fmas_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1) : "vcc");)     \
     X(DIV_FIXUP, "v_div_fixup_f32", 1, asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));)          \
+    X(MOV_B64, "v_mov_b64", 1, asm volatile("v_mov_b64 %0, %1" : "=v"(q[i & 3]) : "v"(q[(i + 1) & 3]));)                        \
+    X(SUBREV_U32, "v_subrev_u32", 1, asm volatile("v_subrev_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));)                         \
+    X(NOT_B32, "v_not_b32", 1, asm volatile("v_not_b32 %0, %0" : "+v"(u[i]));)                                                  \
+    X(ADDC_CO, "v_addc_co_u32", 1, asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(u[i]) : "v"(u[J]) : "vcc");)         \
+    X(MAD_I64_I32, "v_mad_i64_i32", 1, asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(q[i & 3]) : "v"(u[i]), "v"(u[J]) : "vcc");) \
+    X(MUL_I24, "v_mul_i32_i24", 1, asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(u[i]) : "v"(u[J]));)                          \
+    X(WRITELANE, "v_writelane_b32", 1, asm volatile("v_writelane_b32 %0, s10, 3" : "+v"(u[i]));)                                \
+    X(RCP_IFLAG, "v_rcp_iflag_f32", 1, asm volatile("v_rcp_iflag_f32 %0, %0" : "+v"(a[i]));)                                    \
+    X(MAX3_F32, "v_max3_f32", 1, asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));)                     \
+    X(LDEXP_F32, "v_ldexp_f32", 1, asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(a[i]) : "v"(u[J]));)                            \
+    X(LSHRREV_B16, "v_lshrrev_b16", 1, asm volatile("v_lshrrev_b16 %0, 1, %0" : "+v"(u[i]));)                                   \
+    X(CVT_F64_F32, "v_cvt_f64_f32", 1, asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i & 3]) : "v"(a[i]));)                      \
+    X(FMAC_F64, "v_fmac_f64", 1, asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(d[i & 3]) : "v"(dc0), "v"(dc1));)              \
+    X(RCP_F64, "v_rcp_f64", 1, asm volatile("v_rcp_f64 %0, %0" : "+v"(d[i & 3]));)                                              \
     X(FMA_F64, "v_fma_f64", 1, asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i & 3]) : "v"(dc0), "v"(dc1));)                  \
     X(MUL_F64, "v_mul_f64", 1, asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i & 3]) : "v"(dc0));)                               \
     X(ADD_F64, "v_add_f64", 1, asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i & 3]) : "v"(dc1));)                               \
@@ -177,6 +192,7 @@ __global__ void bench(uint64_t* ticks, float* sink, float seed, int reps)
     const float c0 = seed * 0.999f, c1 = seed * 1e-3f;
     const f2 pc0 = f2{c0, c0}, pc1 = f2{c1, c1};
     const double dc0 = (double)c0, dc1 = (double)c1;
+    if constexpr (KIND == CNDMASK_VCC) asm volatile("s_mov_b64 vcc, 0x5555" ::: "vcc");     // a defined condition mask
     __syncthreads();
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
