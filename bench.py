@@ -182,16 +182,20 @@ def k1_roofline(px_per_launch, k1_ms, entry, src):
     r = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
          "traffic": None, "algorithmic_bytes_per_launch": K1_BYTES_PER_PX * px_per_launch, "avg_launch_ms": k1_ms}
     valu = {"mix_ceiling": None, "profile": src,
-            "definition": "mix_ceiling = bare_stream_ms / live launch ms; bare_stream_ms = sum over VALU opcodes of (instructions per wave x measured "
-                          "issue cost: 2-cycle class ~1.0-1.1 ns, 4-cycle class ~1.75-1.8 ns, transcendentals 3.41 ns per wave-instruction per "
-                          "SIMD) x waves / 1024 SIMDs -- what the kernel's VALU instructions alone take with every SIMD issuing back to back; "
-                          "<= 1 by construction (the costs are the cheapest each opcode gets at any occupancy)"}
+            "definition": "mix_ceiling = bare_stream_cycles / launch cycles (GRBM_GUI_ACTIVE / 8), both of the committed PMC run of exactly this "
+                          "code: bare_stream_cycles = sum over VALU opcodes of (instructions per wave x measured issue cost in shader cycles: "
+                          "2-, 4- and 8-cycle classes) x waves / 1024 SIMDs -- what the kernel's VALU instructions alone take with every SIMD "
+                          "issuing back to back; <= 1 by construction, clock-free.  mix_ceiling_ns_live = the same with wall-time costs over "
+                          "the launch time measured live in this run (the micro-benchmark's pure streams hold a lower clock than the kernel's "
+                          "mix, so this one can read a few % high)"}
     if entry:
         d, c, mix = entry["derived"], entry["counters"], entry.get("mix")
         r["traffic"] = d.get("hbm_bytes")
         if mix:
             bare_ms = mix["bare_stream_ns"] * 1e-6
-            valu.update(mix_ceiling=bare_ms / k1_ms, bare_stream_ms=bare_ms, mean_ns_per_instruction=mix["mean_ns_per_instruction"],
+            valu.update(mix_ceiling=d.get("valu_cycles_frac"), bare_stream_cycles=mix.get("bare_stream_cycles"), launch_cycles_profiled=d.get("cycles"),
+                        mean_cycles_per_instruction=mix.get("mean_cycles_per_instruction"),
+                        mix_ceiling_ns_live=bare_ms / k1_ms, bare_stream_ms_at_microbench_clock=bare_ms,
                         class_fractions=mix["class_fractions"], not_in_cost_table_frac=mix["not_in_cost_table_frac"])
         if "SQ_INSTS_VALU" in c:
             slots = c["SQ_INSTS_VALU"] + c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)

@@ -650,6 +650,7 @@ typedef float e_f2 __attribute__((ext_vector_type(2)));
 typedef uint32_t e_u2 __attribute__((ext_vector_type(2)));
 
 constexpr int kE7BX = 32, kE7BY = 8;        // threads; tile = 64 x 8 pixels
+constexpr float kLabelScale = 32.0f;        // labels are compared as floats at this scale (see the staging loop)
 
 struct Enh7PkDev {
     const float* rd;
@@ -704,6 +705,9 @@ __device__ __forceinline__ uint32_t add_byte3(uint32_t w, uint32_t acc)
     return r;
 }
 
+// FUSED_LABEL = false keeps r03's form of the pass-1 label test (weight times a {0,1} mask: one packed instruction more per
+// unit) for the A/B of tools/bench_chain.py (KDE_K10_MASK_PRODUCT=1); the outputs are bit-identical
+template <bool FUSED_LABEL>
 __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkDev a)
 {
     constexpr int WIN = 7, R = 3, HALF = 3, SEGP = 4;
@@ -748,7 +752,10 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
         s_d[i] = valid ? d : 0.0f;
         s_c[i] = c | (valid ? 0x08000000u : 0u);
         s_n[i] = (kMagic + kOff) - dot4u(c, c);
-        s_l[i] = valid ? (float)l : 1.0e9f;          // never within 1 of a label (|label| < 2^24, -1 = unassigned included)
+        // labels are staged at kLabelScale (32) times their value -- exact: |label| < 2^24 -- so that two different labels
+        // differ by >= 32 and (l_q - l_c)^2 >= 1024 can be SUBTRACTED from a log2-domain weight argument to flush it (r04);
+        // an invalid tap never comes near a label (-1 = unassigned included)
+        s_l[i] = valid ? kLabelScale * (float)l : 1.0e12f;
         if (valid) {                                  // positive floats order like their bit patterns
             st_min = min(st_min, __float_as_uint(d));
             st_max = max(st_max, __float_as_uint(d));
@@ -806,8 +813,8 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
         cc[h] = s_c[(ty + R) * P + sx + R + h] & 0x00ffffffu;
         negC[h] = -(kBiasF + (float)dot4u(cc[h], cc[h]));
     }
-    cl.x = (float)in_labels[p];                               // the centre's label counts even if its depth is invalid
-    cl.y = has1 ? (float)in_labels[p + 1] : 2.0e9f;
+    cl.x = kLabelScale * (float)in_labels[p];                 // the centre's label counts even if its depth is invalid
+    cl.y = has1 ? kLabelScale * (float)in_labels[p + 1] : 2.0e12f;
 
     // unit u of a row: (tap of p0, tap of p1) taken from ONE aligned LDS pair -- straight / swapped / leftover
     auto pick_u = [&](const e_u2* v, int u, uint32_t& v0, uint32_t& v1) {
@@ -862,7 +869,17 @@ __global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkD
             const e_f2 nc = unit_ncd(cp, np, u);
             const e_f2 lsj = *reinterpret_cast<const e_f2*>(&a.lsp[(i * WIN + u) * 2]);
             const e_f2 a1 = e_fma(nc, kc1, lsj);
-            const e_f2 f = e_f2{__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)} * label_mask(lp, u);
+            // same-label test folded into the argument (r04; was f * clamp(1 - dl^2): one packed instruction more per unit):
+            // dl == 0 leaves a1 untouched (-0 * 0 + a1), any other label subtracts >= 1024 and v_exp_f32 returns exactly 0 --
+            // the same bits as the product with the {0,1} mask
+            e_f2 f;
+            if constexpr (FUSED_LABEL) {
+                const e_f2 dl = pick_f(lp, u) - cl;
+                const e_f2 a1m = e_fma(-dl, dl, a1);
+                f = e_f2{__builtin_amdgcn_exp2f(a1m.x), __builtin_amdgcn_exp2f(a1m.y)};
+            } else {
+                f = e_f2{__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)} * label_mask(lp, u);
+            }
             wsum = e_fma(pick_f(dp, u), f, wsum);
             wgt = wgt + f;
         }
@@ -1209,8 +1226,10 @@ static int launch_ers_enhance_one(int width, int height, int n, const float* rd,
         for (int k = 49; k >= 1 && d.tthr[k] >= -1.0f; k--) d.kfree = k;
         KDE_STAGE(d.stage_avg = g_stage.ers_avg; d.stage_dev = g_stage.ers_dev; d.stage_counters = g_stage.counters;
                   d.stage_force = g_stage.force_full_rules;)
-        hipLaunchKernelGGL(enhance7_pk_kernel, dim3((unsigned)(ceil_div(width, kE7BX * 2) * ceil_div(height, kE7BY) * n)),
-                           dim3(kE7BX * kE7BY), 0, s, d);
+        static const bool mask_product = getenv("KDE_K10_MASK_PRODUCT") != nullptr;      // A/B switch (r03's pass-1 label test)
+        const dim3 grid((unsigned)(ceil_div(width, kE7BX * 2) * ceil_div(height, kE7BY) * n));
+        if (mask_product) hipLaunchKernelGGL(enhance7_pk_kernel<false>, grid, dim3(kE7BX * kE7BY), 0, s, d);
+        else hipLaunchKernelGGL(enhance7_pk_kernel<true>, grid, dim3(kE7BX * kE7BY), 0, s, d);
         KDE_HIP_TRY(hipGetLastError());
         return KDE_OK;
     }

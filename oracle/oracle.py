@@ -239,7 +239,8 @@ def stage_check(final, st: Stage, rtol=1e-4):
     ndec = int((band & ~grid).sum())            # interval-checked because a tap is ON a decision (not the denormal-grid class)
     expect_avg = have_avg & ~band & ~mismatch   # every strict pixel that has an average must have had it compared
     q = lambda a, m, pc: float(np.percentile(a[m], pc)) if m.any() else 0.0
-    return {"bad": bad, "rel": rel, "n": int(got.size), "band": nb, "grid": int(grid.sum()), "band_decision": ndec,
+    return {"bad": bad, "rel": rel, "avg_unchecked": expect_avg & ~cmp_avg,
+            "n": int(got.size), "band": nb, "grid": int(grid.sum()), "band_decision": ndec,
             "band_frac": nb / max(1, got.size), "band_decision_frac": ndec / max(1, got.size), "grid_frac": int(grid.sum()) / max(1, got.size),
             "avg_checked_of_strict": float((cmp_avg & expect_avg).sum() / max(1, int(expect_avg.sum()))),
             "mismatch": int(mismatch.sum()),

@@ -14,7 +14,7 @@ def test_k1_restatement_passes_its_own_stage_check(oracle, frame, cfg):
     out = oracle.jbf_kernel(depth, bgr, w, ss, cs, ds)
     st = oracle.jbf_stage(depth, bgr, w, ss, cs, ds)                   # avg_in=None: the restatement's own average
     r = oracle.stage_check(out, st)
-    assert not r["bad"].any(), {k: v for k, v in r.items() if k not in ("bad", "rel")}
+    assert not r["bad"].any(), {k: v for k, v in r.items() if k not in ("bad", "rel", "avg_unchecked")}
     assert r["mismatch"] == 0 and r["max_rel_strict"] < 2e-5 and r["avg_bound_frac_max"] < 1.0
     assert r["band_frac"] < 0.02
     # the check has teeth: an average moved by 30 of its bounds, or a final value moved by 3e-4, is rejected
@@ -90,7 +90,7 @@ def test_k10_restatement_passes_its_own_stage_check(oracle, synth, frame, case):
     out = oracle.ers_enhance(rd9, bgr, rl)
     st = oracle.ers_stage(rd9, bgr, rl)
     r = oracle.stage_check(out, st)
-    assert not r["bad"].any(), {k: v for k, v in r.items() if k not in ("bad", "rel")}
+    assert not r["bad"].any(), {k: v for k, v in r.items() if k not in ("bad", "rel", "avg_unchecked")}
     assert r["max_rel_strict"] < 2e-5 and r["avg_bound_frac_max"] < 1.0 and r["dev_bound_frac_max"] < 1.0
     if case == "flat-nan-quirk":
         assert np.isnan(out).sum() > 0 and np.array_equal(np.isnan(out), np.isnan(st.fin64))

@@ -17,11 +17,14 @@ launches of one (kernel name, grid size); derived figures follow /opt/skills/gui
   valu_slot_frac      = (SQ_INSTS_VALU + SQ_INSTS_VALU_TRANS_F32) x 4 / (1024 x cycles): the same 4-cycle model from counts
   mix (r04)           = the kernel's VALU instruction mix priced with the MEASURED issue cost of every opcode
                         (tools/valu_mix.py, profiles/valu_costs.json from tools/valu_microbench):
-                          bare_stream_ns   = sum_m n_m x cost_ns(m) per wave x SQ_WAVES / 1024 SIMDs  -- what the VALU instructions
-                                             alone would take with every SIMD issuing back to back
-                          valu_cycles_frac = bare_stream_ns / duration_ns (duration = End - Start timestamp of the profiled launch)
-                        <= 1 by construction: the costs are the cheapest each opcode gets at any occupancy.  This is the
-                        "fraction of the VALU-issue ceiling" DESIGN.md quotes per kernel.
+                          bare_stream_cycles = sum_m n_m x cycles(m) per wave x SQ_WAVES / 1024 SIMDs -- what the VALU
+                                               instructions alone take with every SIMD issuing back to back
+                          valu_cycles_frac   = bare_stream_cycles / (GRBM_GUI_ACTIVE / 8): both sides in shader cycles of the SAME
+                                               profiled launch, so the clock the chip holds (DVFS) cancels
+                          valu_ns_frac       = the same with the wall-time costs over End - Start of the launch (the micro-benchmark's
+                                               pure streams run at a lower clock than a kernel's mix: can read a few % high)
+                        valu_cycles_frac <= 1 by construction (the costs are the cheapest each opcode gets at any occupancy); it is
+                        the "fraction of the VALU-issue ceiling" DESIGN.md quotes per kernel.
   waves_per_simd      = SQ_WAVE_CYCLES x 4 / (1024 x cycles)                    (mean resident waves per SIMD)
   lds_conflict_frac   = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 `--algo` optionally maps a kernel-name substring to algorithmic bytes per launch so that traffic ratios are in the file."""
@@ -152,7 +155,10 @@ def main():
             mix = valu_mix.estimate(kern_asm[name], costs, c["SQ_INSTS_VALU"] / c["SQ_WAVES"], c.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / c["SQ_WAVES"])
             mix["bare_stream_ns"] = mix["bare_ns_per_wave"] * c["SQ_WAVES"] / 1024.0
             if d.get("duration_ns"):
-                d["valu_cycles_frac"] = mix["bare_stream_ns"] / d["duration_ns"]
+                d["valu_ns_frac"] = mix["bare_stream_ns"] / d["duration_ns"]
+            if "bare_cycles_per_wave" in mix and cyc > 0:
+                mix["bare_stream_cycles"] = mix["bare_cycles_per_wave"] * c["SQ_WAVES"] / 1024.0
+                d["valu_cycles_frac"] = mix["bare_stream_cycles"] / cyc
         if c.get("SQ_LDS_IDX_ACTIVE"):
             d["lds_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
         for sub, nbytes in algo.items():

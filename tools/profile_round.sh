@@ -163,11 +163,15 @@ micro)
   ;;
 micro_pmc)
   # which SQ_INSTS_VALU_* class counter books which opcode (one kernel of the micro-benchmark = one opcode)
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_WAVES \
-      --output-format csv -d "$OUT/micro_pmc/a" -o a -- tools/valu_microbench > "$OUT/micro_pmc_a.log" 2>&1
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_VALU SQ_WAVES \
-      --output-format csv -d "$OUT/micro_pmc/b" -o b -- tools/valu_microbench > "$OUT/micro_pmc_b.log" 2>&1
+  # ... and the issue cost of every opcode in shader CYCLES (GRBM_GUI_ACTIVE / 8 over SQ_INSTS_VALU / 1024 SIMDs): independent of
+  # the clock the chip happens to hold under that load, unlike the wall-time rows of the plain run
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_WAVES GRBM_GUI_ACTIVE \
+      --output-format csv -d "$OUT/micro_pmc/a" -o a -- tools/valu_microbench > "$OUT/micro_pmc_a.txt" 2> "$OUT/micro_pmc_a.log"
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE \
+      --output-format csv -d "$OUT/micro_pmc/b" -o b -- tools/valu_microbench > "$OUT/micro_pmc_b.txt" 2> "$OUT/micro_pmc_b.log"
   find "$OUT/micro_pmc" -name "*.csv" ! -name "*counter_collection.csv" -delete
+  python3 tools/valu_costs.py "$OUT/micro_pmc_a.txt" --pmc-dir "$OUT/micro_pmc" > "$OUT/valu_costs.json"
+  python3 tools/valu_costs.py "$OUT/micro_pmc_a.txt" --pmc-dir "$OUT/micro_pmc" --table
   ;;
 windows)
   # every tuned window next to the generic kernel (one pixel per thread): tools/sweep_jbf.py, 64 x 640x480

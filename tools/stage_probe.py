@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 
 def brief(r):
-    return {k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in r.items() if k not in ("bad", "rel")}
+    return {k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in r.items() if k not in ("bad", "rel", "avg_unchecked")}
 
 
 def main():

@@ -34,9 +34,17 @@ FILES = ("jbf_fast.hip", "jbf_kernels.hip", "ers_kernels.hip", "dasp_kernels.hip
 _CACHE = os.path.join(ROOT, "tools", ".asm_cache")      # git-ignored, travels to the GPU box with the snapshot: no compile there
 
 
+class Costs(dict):
+    """mnemonic -> ns per wave-instruction per SIMD; .cycles: the same in shader cycles (when the table has them)"""
+    cycles = None
+
+
 def load_costs(path=COSTS):
     t = json.load(open(path))
-    return {k: v["ns"] for k, v in t["cost"].items()}
+    c = Costs({k: v["ns"] for k, v in t["cost"].items()})
+    if all("cycles" in v for v in t["cost"].values()):
+        c.cycles = {k: v["cycles"] for k, v in t["cost"].items()}
+    return c
 
 
 def compile_asm(name):
@@ -161,14 +169,17 @@ def estimate(insts, costs, valu_per_wave=None, trans_per_wave=None):
         mix = collections.Counter({k: v * (ft if k.startswith(TRANS) else fr) for k, v in mix.items()})
         how += "; transcendentals = SQ_INSTS_VALU_TRANS_F32, the other opcodes scaled to the rest"
     total = sum(mix.values())
-    bare, unknown, by_class = 0.0, collections.Counter(), collections.Counter()
+    bare, bare_cyc, unknown, by_class = 0.0, 0.0, collections.Counter(), collections.Counter()
+    cyc = getattr(costs, "cycles", None)
     for k, v in mix.items():
         c, known = cost_of(k, costs)
         bare += v * c
+        if cyc:
+            bare_cyc += v * cost_of(k, cyc)[0]
         by_class["8-cycle (transcendental)" if c > 2.6 else "4-cycle" if c > 1.4 else "2-cycle"] += v
         if not known:
             unknown[k] += v
-    r = {"valu_per_wave": total, "bare_ns_per_wave": bare, "mean_ns_per_instruction": bare / max(total, 1e-9), "weighting": how,
+    r = {"valu_per_wave": total, "bare_ns_per_wave": bare, **({"bare_cycles_per_wave": bare_cyc, "mean_cycles_per_instruction": bare_cyc / max(total, 1e-9)} if cyc else {}), "mean_ns_per_instruction": bare / max(total, 1e-9), "weighting": how,
          "static_valu_outside_loops": v0, "static_valu_in_loops": v1,
          "class_fractions": {k: v / max(total, 1e-9) for k, v in sorted(by_class.items())},
          "transcendentals_predicted_by_the_loop_weighting": pred_trans,
