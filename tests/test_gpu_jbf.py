@@ -467,7 +467,7 @@ def test_variant_selection_errors(torch_cuda, F):
     c = torch_cuda.zeros((1, 48, 64, 3), dtype=torch_cuda.uint8, device="cuda")
     o = torch_cuda.empty_like(d)
     jbf.filter_batch(d, c, o)
-    assert torch_cuda.allclose(o, d, rtol=1e-6)
+    assert torch_cuda.allclose(o, d, rtol=1e-5)                    # (a float32 mean of 529 equal taps)
     jbf.set_variant(1)                                             # a window-5 kernel cannot serve window 23
     with pytest.raises(KdeError):
         jbf.filter_batch(d, c, o)

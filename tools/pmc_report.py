@@ -152,7 +152,9 @@ def main():
             d["duration_ns"] = sum(e["dur"]) / len(e["dur"])
         mix = None
         if costs and name in kern_asm and c.get("SQ_WAVES") and "SQ_INSTS_VALU" in c:
-            mix = valu_mix.estimate(kern_asm[name], costs, c["SQ_INSTS_VALU"] / c["SQ_WAVES"], c.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / c["SQ_WAVES"])
+            cls = {k: c["SQ_INSTS_VALU_" + k] / c["SQ_WAVES"] for k in valu_mix.CLASSES if "SQ_INSTS_VALU_" + k in c}
+            mix = valu_mix.estimate(kern_asm[name], costs, c["SQ_INSTS_VALU"] / c["SQ_WAVES"], c.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / c["SQ_WAVES"],
+                                    cls if len(cls) == len(valu_mix.CLASSES) else None)
             mix["bare_stream_ns"] = mix["bare_ns_per_wave"] * c["SQ_WAVES"] / 1024.0
             if d.get("duration_ns"):
                 d["valu_ns_frac"] = mix["bare_stream_ns"] / d["duration_ns"]

@@ -35,8 +35,40 @@ _CACHE = os.path.join(ROOT, "tools", ".asm_cache")      # git-ignored, travels t
 
 
 class Costs(dict):
-    """mnemonic -> ns per wave-instruction per SIMD; .cycles: the same in shader cycles (when the table has them)"""
+    """mnemonic -> ns per wave-instruction per SIMD; .cycles: the same in shader cycles (when the table has them);
+    .klass: mnemonic -> the SQ_INSTS_VALU_* class counter that books it (measured: tools/profile_round.sh micro_pmc)"""
     cycles = None
+    klass = None
+
+
+CLASSES = ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "INT64", "CVT")
+
+
+def class_of(m, costs):
+    """which SQ_INSTS_VALU_<class> counter books opcode m ("OTHER": none of them -- moves, logic ops, shifts, selects, f32
+    compares / min / max, lane ops, f64).  Measured per opcode where the micro-benchmark covers it, by family otherwise."""
+    n = norm(m)
+    k = getattr(costs, "klass", None) or {}
+    if n in k:
+        return k[n]
+    if n.startswith(TRANS):
+        return "TRANS_F32" if n.endswith("f32") else "OTHER"
+    if n.startswith("v_cvt_"):
+        return "CVT"
+    if re.search(r"(f64|f16|u16|i16|b16)(_sdwa|_dpp)?$", n):
+        return "OTHER"
+    if re.match(r"v_(pk_)?(add|sub|subrev)_f32", n):
+        return "ADD_F32"
+    if re.match(r"v_(pk_)?mul_f32", n):
+        return "MUL_F32"
+    if re.match(r"v_(pk_)?(fma|fmac|fmamk|fmaak|mad|mac)_f32|v_div_fmas_f32", n):
+        return "FMA_F32"
+    if re.search(r"(u64|i64)", n) and not n.startswith(("v_cmp", "v_lshr", "v_lshl", "v_ashr")):
+        return "INT64"
+    if re.match(r"v_(add|sub|subrev|addc|subb|subbrev|mul|mad|min|max|min3|max3|med3|bfe|dot4|dot2|sad|lshl_add|add_lshl|add3|ashrrev|mbcnt|xad)"
+                r"(_co)?(_lo|_hi)?_?(u32|i32|u32_u24|i32_i24|u32_u8|i32_i8|u32_b32|lshl_u32|add_u32)", n) or re.match(r"v_cmp_\w+_(i32|u32)", n):
+        return "INT32"
+    return "OTHER"
 
 
 def load_costs(path=COSTS):
@@ -44,6 +76,10 @@ def load_costs(path=COSTS):
     c = Costs({k: v["ns"] for k, v in t["cost"].items()})
     if all("cycles" in v for v in t["cost"].values()):
         c.cycles = {k: v["cycles"] for k, v in t["cost"].items()}
+        c.klass = {}
+        for k, v in t["cost"].items():
+            booked = [n[len("SQ_INSTS_VALU_"):] for n, x in v.get("counted_by", {}).items() if n.startswith("SQ_INSTS_VALU_") and x > 0.5]
+            c.klass[k] = booked[0] if booked else "OTHER"
     return c
 
 
@@ -139,8 +175,11 @@ def cost_of(m, costs):
     return min(costs.values()), False
 
 
-def estimate(insts, costs, valu_per_wave=None, trans_per_wave=None):
-    """price one kernel.  insts: [(mnemonic, in_loop)] (parse_body)."""
+def estimate(insts, costs, valu_per_wave=None, trans_per_wave=None, classes_per_wave=None):
+    """price one kernel.  insts: [(mnemonic, in_loop)] (parse_body).  classes_per_wave: {"ADD_F32": n, ...} = the hardware's
+    SQ_INSTS_VALU_<class> counts per wave: the histogram is then scaled CLASS BY CLASS to what the hardware counted (the opcodes
+    no class counter books take the rest of SQ_INSTS_VALU), so that only the split between the members of one class is left to
+    the static code -- kernels whose branches skip part of the code (K7's pruned candidates) are otherwise mispriced."""
     valu = [(m, lp) for m, lp in insts if m.startswith("v_")]
     h0 = collections.Counter(norm(m) for m, lp in valu if not lp)
     h1 = collections.Counter(norm(m) for m, lp in valu if lp)
@@ -161,7 +200,26 @@ def estimate(insts, costs, valu_per_wave=None, trans_per_wave=None):
     for k, v in h1.items():
         mix[k] += v * x
     pred_trans = sum(v for k, v in mix.items() if k.startswith(TRANS))
-    if valu_per_wave and trans_per_wave is not None and pred_trans > 0 and trans_per_wave > 0:
+    by_counter = None
+    if valu_per_wave and classes_per_wave:
+        stat = collections.Counter()
+        for k, v in mix.items():
+            stat[class_of(k, costs)] += v
+        target = {c: float(classes_per_wave.get(c, 0.0)) for c in CLASSES}
+        target["OTHER"] = max(0.0, valu_per_wave - sum(target.values()))
+        scaled = collections.Counter()
+        for k, v in mix.items():
+            c = class_of(k, costs)
+            if stat[c] > 0:
+                scaled[k] = v * target[c] / stat[c]
+        # a class the hardware counted but the static code does not show (or the reverse) is left to the cheapest opcode
+        missing = sum(t for c, t in target.items() if stat[c] <= 0)
+        if missing > 0:
+            scaled["v_mov_b32"] += missing
+        by_counter = {c: {"counted": round(target[c], 1), "static_share_scaled_from": round(stat[c], 1)} for c in target if target[c] > 0 or stat[c] > 0}
+        mix = scaled
+        how += "; then every SQ_INSTS_VALU_<class> scaled to the hardware's count (opcodes no class books: the rest of SQ_INSTS_VALU)"
+    elif valu_per_wave and trans_per_wave is not None and pred_trans > 0 and trans_per_wave > 0:
         # the transcendentals are counted by the hardware (SQ_INSTS_VALU_TRANS_F32): take that count for them (split among the
         # transcendental opcodes as in the histogram) and scale the other opcodes to the rest of SQ_INSTS_VALU
         rest = sum(v for k, v in mix.items() if not k.startswith(TRANS))
@@ -187,6 +245,8 @@ def estimate(insts, costs, valu_per_wave=None, trans_per_wave=None):
          "top": [[k, round(v, 1)] for k, v in mix.most_common(10)]}
     if trans_per_wave is not None:
         r["transcendentals_counted_per_wave"] = trans_per_wave
+    if by_counter:
+        r["classes"] = by_counter
     if unknown:
         r["not_in_cost_table"] = [[k, round(v, 1)] for k, v in unknown.most_common(6)]
     return r
