@@ -19,11 +19,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # largest admissible fraction of a frame (>= 64x48 pixels) that may be interval-checked because a tap lies ON a Q1 decision
 # (the non-GRID part of the BAND class); smaller frames are too few pixels for a fraction to mean anything
-DECISION_MAX = 0.02
+DECISION_MAX = 0.005          # (4000 cases, seed 601: max 3.2e-3, p99 5.2e-4)
+BAND_MAX = 0.1                 # the whole interval-checked class incl. the denormal-grid part (same run: max 5.1e-2, p99 1.6e-3)
 
 
 def _dmax(w, h):
     return DECISION_MAX if w * h >= 64 * 48 else None
+
+
+def _bmax(w, h):
+    return BAND_MAX if w * h >= 64 * 48 else 1.0
 
 
 def run(cases=100, seed=1, dump="", ers=False, only=""):
@@ -84,7 +89,7 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
                         raise
                     state["got"] = host(out)[0].copy()
                     state["variant"] = np.array([v])
-                    assert_k1_stagewise(p, depth, bgr, state["got"], variant=v, what=f"K1 v{v} win {win} sig {ss}/{cs}/{ds}", band_max=1.0, decision_max=_dmax(w, h))
+                    assert_k1_stagewise(p, depth, bgr, state["got"], variant=v, what=f"K1 v{v} win {win} sig {ss}/{cs}/{ds}", band_max=_bmax(w, h), decision_max=_dmax(w, h))
                     assert_depth_close(state["got"], ref, 1e-4, ill=ill, what=f"K1 v{v} win {win} sig {ss}/{cs}/{ds}")
                 desc = f"k1 {w}x{h} win {win} sig {ss}/{cs}/{ds} variants {len(cands)}"
             elif kind == "k0":
@@ -241,7 +246,7 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
                     assert np.array_equal(host(ers.getRefinedLabels_Device()), el), f"ERS v{v} refined labels"
                     assert np.array_equal(host(ers.getEdgeStageDepth_Device()), ed), f"ERS v{v} depth after edge_refining"
                     state["got"] = host(ers.getRefinedDepth_Device()).copy()
-                    assert_k10_stagewise(cl, dl, depth, bgr, state["got"], variant=v, what=f"ERS v{v} refined depth", band_max=1.0, decision_max=_dmax(w, h))
+                    assert_k10_stagewise(cl, dl, depth, bgr, state["got"], variant=v, what=f"ERS v{v} refined depth", band_max=_bmax(w, h), decision_max=_dmax(w, h))
                     assert_depth_close(state["got"], rd, 1e-4, ill=ill, what=f"ERS v{v} refined depth")
                 desc = f"ers {w}x{h} regions {k} jitter {jit:.1f}"
             elif kind == "spdsr":
@@ -264,7 +269,7 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
                 got = host(sr.getRefinedDepth_Device())
                 sp_l = O.dasp_segmentation(bgr, pts, rows, cols, K, 200.0, 10.0, 0.0, 5)[0]
                 da_l = O.dasp_segmentation(bgr, pts, rows, cols, K, 0.0, 10.0, 200.0, 5)[0]
-                assert_k10_stagewise(sp_l, da_l, depth, bgr, got, what="SPDSR head depth", band_max=1.0, decision_max=_dmax(w, h))
+                assert_k10_stagewise(sp_l, da_l, depth, bgr, got, what="SPDSR head depth", band_max=_bmax(w, h), decision_max=_dmax(w, h))
                 assert_depth_close(got, rd, 1e-4, ill=ill, what="SPDSR head depth")
                 gpts = host(sr.getEdgeEnhanced3DPoints_Device())
                 gp = np.ascontiguousarray(gpts).view(O.FLOAT3).reshape(h, w)
@@ -305,7 +310,7 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
                 state.update(bgr=bgr, depth=depth, ref=ref["refined_depth"], labels=ref["refined_labels"], **ill.to_dict("env"),
                              params=np.array([rows, cols]), got=host(rg.getRefinedDepth_Device()).copy(),
                              stage=host(rg.getEdgeStageDepth_Device()).copy() if hasattr(rg, "getEdgeStageDepth_Device") else np.zeros(1))
-                assert_k10_stagewise(ref["sp_labels"], ref["dasp_labels"], depth, bgr, state["got"], what=f"RGBF depth grid {rows}x{cols}", band_max=1.0, decision_max=_dmax(w, h))
+                assert_k10_stagewise(ref["sp_labels"], ref["dasp_labels"], depth, bgr, state["got"], what=f"RGBF depth grid {rows}x{cols}", band_max=_bmax(w, h), decision_max=_dmax(w, h))
                 assert_depth_close(state["got"], ref["refined_depth"], 1e-4, ill=ill, what=f"RGBF depth grid {rows}x{cols}")
                 desc = f"rgbf {w}x{h} grid {rows}x{cols}"
             print(f"[{case}] ok   {desc}", flush=True)
