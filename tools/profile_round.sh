@@ -27,16 +27,18 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE"
 # the hardware's own split of SQ_INSTS_VALU by class: tools/valu_mix.py scales the static histogram class by class to these
-SQ3="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"
+# (the SQ block has 8 counter slots: SQ_WAVES / SQ_INSTS_VALU come from the SQ1 pass of the same command)
+SQ3="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE"
 SQ2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"
 
 pmc_passes() {   # <subdir> <program> <args...>: five passes of the same command
   local sub=$1; shift
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$sub/fetch" -o fetch -- "$@" > "$OUT/$sub.fetch.log" 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$sub/write" -o write -- "$@" > "$OUT/$sub.write.log" 2>&1
-  rocprofv3 --pmc $SQ1 --output-format csv -d "$OUT/$sub/sq1" -o sq1 -- "$@" > "$OUT/$sub.sq1.log" 2>&1
-  rocprofv3 --pmc $SQ2 --output-format csv -d "$OUT/$sub/sq2" -o sq2 -- "$@" > "$OUT/$sub.sq2.log" 2>&1
-  rocprofv3 --pmc $SQ3 --output-format csv -d "$OUT/$sub/sq3" -o sq3 -- "$@" > "$OUT/$sub.sq3.log" 2>&1
+  # (every pass under its own time limit: a profiler that aborts has been seen to hang instead of exiting)
+  timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$sub/fetch" -o fetch -- "$@" > "$OUT/$sub.fetch.log" 2>&1
+  timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$sub/write" -o write -- "$@" > "$OUT/$sub.write.log" 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $SQ1 --output-format csv -d "$OUT/$sub/sq1" -o sq1 -- "$@" > "$OUT/$sub.sq1.log" 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $SQ2 --output-format csv -d "$OUT/$sub/sq2" -o sq2 -- "$@" > "$OUT/$sub.sq2.log" 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $SQ3 --output-format csv -d "$OUT/$sub/sq3" -o sq3 -- "$@" > "$OUT/$sub.sq3.log" 2>&1
   find "$OUT/$sub" -name "*.csv" ! -name "*counter_collection.csv" -delete
 }
 
