@@ -1,9 +1,9 @@
 #!/bin/bash
 # Copies what tools/profile_round.sh <tag> left under gpurun_out/<tag>/ (scratch) into profiles/ (tracked) under the
-# names DESIGN.md quotes.   tools/collect_profiles.sh <tag> [round-prefix, default r03]
+# names DESIGN.md quotes.   tools/collect_profiles.sh <tag> [round-prefix, default r04]
 set -eo pipefail
 TAG=${1:?tag}
-R=${2:-r03}
+R=${2:-r04}
 S=gpurun_out/$TAG
 D=profiles
 cpif() { [ -f "$1" ] && cp "$1" "$2" && echo "  $2" || true; }
@@ -26,4 +26,7 @@ cpif $S/mrf_vga.json $D/${R}_mrf_vga.json
 cpif $S/feeders.json $D/${R}_feeders_128xfhd.json
 cpif $S/shard_vs_bench.json $D/${R}_shard_replay_vs_bench_1gpu.json
 cpif $S/sweep_k1_variants.log $D/${R}_sweep_k1_variants.log
-cpif $S/valu_microbench.txt $D/${R}_valu_microbench.txt
+cpif $S/micro_pmc_a.txt $D/${R}_valu_microbench.txt
+# (profiles/valu_costs.json needs the micro_pmc step -- cycles per opcode -- and is only copied from a round that ran it)
+[ -d $S/micro_pmc ] && cpif $S/valu_costs.json $D/valu_costs.json
+cpif $S/sweep_k1_windows.log $D/${R}_sweep_k1_windows.log

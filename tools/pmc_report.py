@@ -20,7 +20,12 @@ launches of one (kernel name, grid size); derived figures follow /opt/skills/gui
                           bare_stream_cycles = sum_m n_m x cycles(m) per wave x SQ_WAVES / 1024 SIMDs -- what the VALU
                                                instructions alone take with every SIMD issuing back to back
                           valu_cycles_frac   = bare_stream_cycles / (GRBM_GUI_ACTIVE / 8): both sides in shader cycles of the SAME
-                                               profiled launch, so the clock the chip holds (DVFS) cancels
+                                               profiled launch, so the clock the chip holds (DVFS) cancels.  cycles(m) = the issue
+                                               rate of the opcode's measured class: 2, 4, 8 (16: v_rcp_f64) cycles
+                          valu_cycles_frac_at_measured_costs = the same with the micro-benchmark's own figures (2.3-2.5 / 4.1-4.4 /
+                                               8.2: they carry its loop overhead and operand-read stalls, so this one can exceed 1)
+                          valu_cycles_floor_frac = counters only, no assembly: (2 x non-transcendental + 8 x transcendental
+                                               instructions) / 1024 / cycles -- what no mix estimate can fall below
                           valu_ns_frac       = the same with the wall-time costs over End - Start of the launch (the micro-benchmark's
                                                pure streams run at a lower clock than a kernel's mix: can read a few % high)
                         valu_cycles_frac <= 1 by construction (the costs are the cheapest each opcode gets at any occupancy); it is
@@ -161,6 +166,11 @@ def main():
             if "bare_cycles_per_wave" in mix and cyc > 0:
                 mix["bare_stream_cycles"] = mix["bare_cycles_per_wave"] * c["SQ_WAVES"] / 1024.0
                 d["valu_cycles_frac"] = mix["bare_stream_cycles"] / cyc
+                d["valu_cycles_frac_at_measured_costs"] = mix["bare_cycles_per_wave_at_measured_costs"] * c["SQ_WAVES"] / 1024.0 / cyc
+                # rigorous floor, counters only: every instruction at the cheapest rate (2 cycles), the hardware-counted
+                # transcendentals at 8
+                tr_ = c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+                d["valu_cycles_floor_frac"] = (2.0 * (c["SQ_INSTS_VALU"] - tr_) + 8.0 * tr_) / 1024.0 / cyc
         if c.get("SQ_LDS_IDX_ACTIVE"):
             d["lds_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
         for sub, nbytes in algo.items():

@@ -163,7 +163,6 @@ PY
   ;;
 micro)
   tools/valu_microbench > "$OUT/valu_microbench.txt" 2>&1
-  python3 tools/valu_costs.py "$OUT/valu_microbench.txt" > "$OUT/valu_costs.json"
   python3 tools/valu_costs.py "$OUT/valu_microbench.txt" --table
   ;;
 micro_pmc)

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """BASELINE's workloads at their own sizes on MANY synthetic frames (tests/test_gpu_fullsize.py checks one frame each):
 JointBilateralFilter::Process at 640x480 / window 11 (config 2 / 4) and 1920x1080 / window 19 (config 3), and the config-5
-chain at 640x480, every frame under the stage-wise check (the oracle is the checker, as in tests/).  Every pixel of every frame has to pass; the
-fraction of interval-checked (BAND) pixels per frame is reported, not capped.
+chain at 640x480, every frame under the stage-wise check (the oracle is the checker, as in tests/).  Every pixel of every frame has to pass.  The
+part of a frame that is interval-checked because a tap lies ON a Q1 decision (BAND without GRID) is ASSERTED <= 1e-4 per frame --
+the bound the full-size tests use, here for the generator, not for a few seeds; the denormal-grid part (content: holes whose
+whole window differs in colour) is reported.
     python tools/stress_fullsize.py [--vga 16] [--fhd 3] [--chain 6] [--seed 1000]"""
 import argparse
 import os
@@ -30,7 +32,8 @@ def main():
     O.build()
     O.set_threads(min(16, os.cpu_count() or 1))
     bad = 0
-    fracs = {}       # what -> list of (BAND fraction, strict max rel err)
+    fracs = {}       # what -> list of (BAND fraction, strict max rel err, decision fraction)
+    DECISION_MAX = 1e-4
 
     def params(w):
         p = F.JointBilateralFilter.default_params()
@@ -47,9 +50,9 @@ def main():
         for f in range(count):
             try:
                 assert np.array_equal(smooth[f], O.cv_bilateral(bgr[f], 5, 30.0, 30.0)), "K0 bytes differ"
-                r = assert_k1_stagewise(jbf.params, depth[f], smooth[f], out[f], what=f"{tag} seed {a.seed + f}", band_max=1.0)
-                fracs.setdefault(tag, []).append((r["band_frac"], r["max_rel_strict"]))
-                print(f"ok   {tag} {W}x{H} window {win} seed {a.seed + f}: BAND {r['band_frac']:.2e}, strict {r['max_rel_strict']:.2e}", flush=True)
+                r = assert_k1_stagewise(jbf.params, depth[f], smooth[f], out[f], what=f"{tag} seed {a.seed + f}", band_max=1.0, decision_max=DECISION_MAX)
+                fracs.setdefault(tag, []).append((r["band_frac"], r["max_rel_strict"], r["band_decision_frac"]))
+                print(f"ok   {tag} {W}x{H} window {win} seed {a.seed + f}: BAND {r['band_frac']:.2e} (on a decision {r['band_decision_frac']:.2e}), strict {r['max_rel_strict']:.2e}", flush=True)
             except AssertionError as e:
                 bad += 1
                 print(f"FAIL {tag} seed {a.seed + f}: {str(e)[:300]}", flush=True)
@@ -73,16 +76,17 @@ def main():
             assert np.array_equal(host(rg.getDASPLabels_Device()), ref["dasp_labels"]), "DASP labels differ"
             assert np.array_equal(host(rg.getRefinedLabels_Device()), ref["refined_labels"]), "refined labels differ"
             r = assert_k10_stagewise(ref["sp_labels"], ref["dasp_labels"], got_filt, bgr, host(rg.getRefinedDepth_Device()),
-                                     what=f"config 5 chain seed {a.seed + 500 + f}", band_max=1.0)
-            fracs.setdefault("config 5 (K10)", []).append((r["band_frac"], r["max_rel_strict"]))
-            print(f"ok   config 5 chain 640x480 seed {a.seed + 500 + f}: BAND {r['band_frac']:.2e}, strict {r['max_rel_strict']:.2e}", flush=True)
+                                     what=f"config 5 chain seed {a.seed + 500 + f}", band_max=1.0, decision_max=DECISION_MAX)
+            fracs.setdefault("config 5 (K10)", []).append((r["band_frac"], r["max_rel_strict"], r["band_decision_frac"]))
+            print(f"ok   config 5 chain 640x480 seed {a.seed + 500 + f}: BAND {r['band_frac']:.2e} (on a decision {r['band_decision_frac']:.2e}), strict {r['max_rel_strict']:.2e}", flush=True)
         except AssertionError as e:
             bad += 1
             print(f"FAIL chain seed {a.seed + 500 + f}: {str(e)[:300]}", flush=True)
     for tag, v in fracs.items():
-        b = np.array([x[0] for x in v]); e = np.array([x[1] for x in v])
+        b = np.array([x[0] for x in v]); e = np.array([x[1] for x in v]); dcs = np.array([x[2] for x in v])
         print(f"{tag}: {len(v)} frames, BAND fraction median {np.median(b):.2e} p90 {np.percentile(b, 90):.2e} max {b.max():.2e} "
-              f"({int((b > 0.003).sum())} frames above 0.3 %); strict-pixel max rel err median {np.median(e):.2e} max {e.max():.2e}")
+              f"({int((b > 0.003).sum())} frames above 0.3 %); of it on a decision (asserted <= {DECISION_MAX:g} per frame): median {np.median(dcs):.2e} "
+              f"max {dcs.max():.2e}; strict-pixel max rel err median {np.median(e):.2e} max {e.max():.2e}")
     print(f"stress_fullsize: {a.vga} + {a.fhd} + {a.chain} frames, {bad} violations")
     return 1 if bad else 0
 

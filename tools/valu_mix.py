@@ -38,6 +38,7 @@ class Costs(dict):
     """mnemonic -> ns per wave-instruction per SIMD; .cycles: the same in shader cycles (when the table has them);
     .klass: mnemonic -> the SQ_INSTS_VALU_* class counter that books it (measured: tools/profile_round.sh micro_pmc)"""
     cycles = None
+    nominal = None
     klass = None
 
 
@@ -76,6 +77,9 @@ def load_costs(path=COSTS):
     c = Costs({k: v["ns"] for k, v in t["cost"].items()})
     if all("cycles" in v for v in t["cost"].values()):
         c.cycles = {k: v["cycles"] for k, v in t["cost"].items()}
+        # the issue rate behind each measured cost: 2 / 4 / 8 / 16 SIMD-32 cycles (the measured 2.3-2.5 / 4.1-4.4 / 8.2 / 16.2 carry the
+        # micro-benchmark's own loop overhead and operand-read stalls; a CEILING must not include them)
+        c.nominal = {k: min((2.0, 4.0, 8.0, 16.0), key=lambda n: abs(n - v) / n) for k, v in c.cycles.items()}
         c.klass = {}
         for k, v in t["cost"].items():
             booked = [n[len("SQ_INSTS_VALU_"):] for n, x in v.get("counted_by", {}).items() if n.startswith("SQ_INSTS_VALU_") and x > 0.5]
@@ -142,14 +146,18 @@ def parse_body(body):
             continue
         if re.match(r"^[a-z_0-9]+", t):
             insts.append((t.split()[0], t))
-    in_loop = [False] * len(insts)
+    # loops = backward branches; several branches to one label (continue paths) are ONE loop: its extent runs to the last of them
+    extent = {}
     for i, (m, t) in enumerate(insts):
         if m.startswith("s_cbranch") or m == "s_branch":
             tgt = t.split()[-1]
             if tgt in labels and labels[tgt] <= i:
-                for j in range(labels[tgt], i + 1):
-                    in_loop[j] = True
-    return [(m, lp) for (m, _), lp in zip(insts, in_loop)]
+                extent[labels[tgt]] = max(extent.get(labels[tgt], -1), i)
+    depth = [0] * len(insts)            # number of loops enclosing the instruction
+    for lo, hi in extent.items():
+        for j in range(lo, hi + 1):
+            depth[j] += 1
+    return [(m, dp) for (m, _), dp in zip(insts, depth)]
 
 
 def cost_of(m, costs):
@@ -180,25 +188,34 @@ def estimate(insts, costs, valu_per_wave=None, trans_per_wave=None, classes_per_
     SQ_INSTS_VALU_<class> counts per wave: the histogram is then scaled CLASS BY CLASS to what the hardware counted (the opcodes
     no class counter books take the rest of SQ_INSTS_VALU), so that only the split between the members of one class is left to
     the static code -- kernels whose branches skip part of the code (K7's pruned candidates) are otherwise mispriced."""
-    valu = [(m, lp) for m, lp in insts if m.startswith("v_")]
-    h0 = collections.Counter(norm(m) for m, lp in valu if not lp)
-    h1 = collections.Counter(norm(m) for m, lp in valu if lp)
-    v0, v1 = sum(h0.values()), sum(h1.values())
+    valu = [(m, int(lp)) for m, lp in insts if m.startswith("v_")]
+    maxd = max([d for _, d in valu], default=0)
+    hd = [collections.Counter(norm(m) for m, d in valu if d == k) for k in range(maxd + 1)]
+    vd = [sum(h.values()) for h in hd]
+    v0, v1 = vd[0], sum(vd[1:])
     x, how = 1.0, "static histogram (no loops or no counters)"
     if valu_per_wave and v1 > 0 and valu_per_wave > v0 + v1:
-        x = (valu_per_wave - v0) / v1
-        how = f"loop bodies x {x:.2f} so that the total is SQ_INSTS_VALU / SQ_WAVES"
+        # one common trip factor x per loop level: an instruction inside d nested loops is weighted x^d, x such that the total
+        # is the hardware's dynamic count per wave
+        lo, hi = 1.0, 1.0e6
+        for _ in range(200):
+            x = 0.5 * (lo + hi)
+            if sum(v * x ** d for d, v in enumerate(vd)) > valu_per_wave:
+                hi = x
+            else:
+                lo = x
+        how = f"an instruction inside d nested loops x {x:.2f}^d so that the total is SQ_INSTS_VALU / SQ_WAVES"
+        scale = [x ** d for d in range(maxd + 1)]
     elif valu_per_wave:
-        x = valu_per_wave / max(1, v0 + v1)                    # straight-line code with branches: the whole body scaled
-        h0 = collections.Counter({k: v * x for k, v in h0.items()})
-        h1 = collections.Counter({k: v * x for k, v in h1.items()})
-        how = f"whole body x {x:.2f} (branches / early exits) so that the total is SQ_INSTS_VALU / SQ_WAVES"
-        x = 1.0
+        f = valu_per_wave / max(1, v0 + v1)                    # straight-line code with branches: the whole body scaled
+        how = f"whole body x {f:.2f} (branches / early exits) so that the total is SQ_INSTS_VALU / SQ_WAVES"
+        scale = [f] * (maxd + 1)
+    else:
+        scale = [1.0] * (maxd + 1)
     mix = collections.Counter()
-    for k, v in h0.items():
-        mix[k] += v
-    for k, v in h1.items():
-        mix[k] += v * x
+    for d, h in enumerate(hd):
+        for k, v in h.items():
+            mix[k] += v * scale[d]
     pred_trans = sum(v for k, v in mix.items() if k.startswith(TRANS))
     by_counter = None
     if valu_per_wave and classes_per_wave:
@@ -227,17 +244,19 @@ def estimate(insts, costs, valu_per_wave=None, trans_per_wave=None, classes_per_
         mix = collections.Counter({k: v * (ft if k.startswith(TRANS) else fr) for k, v in mix.items()})
         how += "; transcendentals = SQ_INSTS_VALU_TRANS_F32, the other opcodes scaled to the rest"
     total = sum(mix.values())
-    bare, bare_cyc, unknown, by_class = 0.0, 0.0, collections.Counter(), collections.Counter()
-    cyc = getattr(costs, "cycles", None)
+    bare, bare_cyc, bare_nom, unknown, by_class = 0.0, 0.0, 0.0, collections.Counter(), collections.Counter()
+    cyc, nom = getattr(costs, "cycles", None), getattr(costs, "nominal", None)
     for k, v in mix.items():
         c, known = cost_of(k, costs)
         bare += v * c
         if cyc:
             bare_cyc += v * cost_of(k, cyc)[0]
+            bare_nom += v * cost_of(k, nom)[0]
         by_class["8-cycle (transcendental)" if c > 2.6 else "4-cycle" if c > 1.4 else "2-cycle"] += v
         if not known:
             unknown[k] += v
-    r = {"valu_per_wave": total, "bare_ns_per_wave": bare, **({"bare_cycles_per_wave": bare_cyc, "mean_cycles_per_instruction": bare_cyc / max(total, 1e-9)} if cyc else {}), "mean_ns_per_instruction": bare / max(total, 1e-9), "weighting": how,
+    r = {"valu_per_wave": total, "bare_ns_per_wave": bare, **({"bare_cycles_per_wave": bare_nom, "mean_cycles_per_instruction": bare_nom / max(total, 1e-9),
+            "bare_cycles_per_wave_at_measured_costs": bare_cyc} if cyc else {}), "mean_ns_per_instruction": bare / max(total, 1e-9), "weighting": how,
          "static_valu_outside_loops": v0, "static_valu_in_loops": v1,
          "class_fractions": {k: v / max(total, 1e-9) for k, v in sorted(by_class.items())},
          "transcendentals_predicted_by_the_loop_weighting": pred_trans,
