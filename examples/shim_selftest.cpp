@@ -86,6 +86,15 @@ int main()
     sr.SetParametor(6, 8, K);
     expect(throws_invalid([&] { jbf.Process(d_depth, padded); }) && throws_invalid([&] { jbf.Process(d_depth, wrong); }), "JBF rejects padded / wrong-size images");
     expect(throws_invalid([&] { mrf.Process(d_depth, padded); }), "MRF rejects a padded image");
+    {   // which kernel an object runs (kde_jbf_active_variant): the reference constants select a tuned window-5 kernel, a
+        // window of 23 the generic one
+        kde_jbf_params wide;
+        kde_jbf_default_params(&wide);
+        wide.window_size = 23;
+        JointBilateralFilter jbf23(W, H, wide);
+        expect(std::strncmp(jbf.activeKernel(), "w5-pk", 5) == 0 && std::strcmp(jbf23.activeKernel(), "generic-32x8-1px") == 0,
+               "activeKernel() names the tuned / generic kernel");
+    }
     expect(throws_invalid([&] { dasp.Segmentation(padded, d_pts, 200.f, 40.f, 0.f, 1); }) &&
                throws_invalid([&] { dasp.Segmentation(wrong, d_pts, 200.f, 40.f, 0.f, 1); }), "DASP rejects padded / wrong-size images");
     dasp.Segmentation(good, d_pts, 200.f, 40.f, 0.f, 1);

@@ -143,6 +143,14 @@ public:
     }
     void setStream(void* hip_stream) { stream_ = hip_stream; }
     kde_jbf* handle() const { return h_; }
+    // extension: the name of the kernel this object's parameters select ("generic-32x8-1px" when no tuned one applies:
+    // windows 1 and 23-31, a zero sigma); kde_jbf_active_variant
+    const char* activeKernel() const
+    {
+        int v = 0;
+        check(kde_jbf_active_variant(h_, &v));
+        return kde_jbf_variant_name(v);
+    }
 
 private:
     int Width, Height;
