@@ -120,7 +120,8 @@ int kde_jbf_spatial_table(kde_jbf* h, float* table_host, int capacity);
 int kde_jbf_set_variant(kde_jbf* h, int variant);
 /* which kernel kde_jbf_process / kde_jbf_filter_batch will launch for this handle's parameters and variant setting:
  * an index into kde_jbf_variant_name(); 0 = "generic-32x8-1px" (one pixel per thread, any odd window <= 31, zero sigmas).
- * Tuned kernels exist for windows 3, 5, 7, 9, 11, 13, 15, 17, 19, 21 with non-zero sigmas; the reference takes
+ * Tuned kernels exist for every odd window from 3 to 31 with non-zero sigmas (23..31 read their log2(S) table from a device
+ * copy the handle uploads at creation: it no longer fits the 4 KB kernel-argument block); the reference takes
  * window_size as a run-time argument (JointBilateralFilter.cu:10,18-19) */
 int kde_jbf_active_variant(kde_jbf* h, int* variant);
 int kde_jbf_variant_count(void);

@@ -55,8 +55,10 @@ struct FastArgs {
     // log2 of the spatial table (zeros of the table -> factor skipped -> log2 = 0).  Scalar kernels read
     // tab[i*WIN + j]; packed kernels read the pair (ls[i][j of p0], ls[i][j of p1]) of unit u at
     // tab[(i*WIN + u)*2 .. +1], so the addend of the argument fma is one aligned SGPR pair.
-    // 21 x 21 x 2 floats: the widest tuned window.  The whole struct is the kernel's argument block and stays below HIP's 4 KB
-    // limit for it (window 23 would need 4232 bytes for the table alone): wider windows take the generic kernel
+    // 21 x 21 x 2 floats.  The whole struct is the kernel's argument block and stays below HIP's 4 KB limit for it (window 23
+    // would need 4232 bytes for the table alone): windows 23..31 read the same pairs from tab_dev, a device copy the handle
+    // uploaded once (still wave-uniform addresses: scalar loads)
+    const float* tab_dev;
     __attribute__((aligned(8))) float tab[882];
 };
 
@@ -269,8 +271,10 @@ __device__ __forceinline__ f2 pk_mul_clamp(f2 a, f2 b)
 
 // second launch bound = waves per SIMD the register allocator must leave room for: the four rule-specialised bodies
 // below share one kernel, and without it the window-19 instance grew from 131 to 182 VGPRs (3 -> 2 waves per SIMD)
+// (windows >= 23: at least 3 waves per SIMD, i.e. <= 168 VGPRs -- without the bound the instances without the colour rule
+//  came out at 228 / 248 registers, 2 waves per SIMD)
 template <int WIN, int NP, int BX, int BY, bool CACHE, bool CSKIP, bool VL, bool ELIDE_ON = true>
-__global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
+__global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 23 ? 3 : 1))) void jbf_pk_kernel(const FastArgs a)
 {
     constexpr int R = WIN / 2;
     constexpr int PX = 2 * NP;
@@ -513,7 +517,16 @@ __global__ __launch_bounds__(BX* BY) void jbf_pk_kernel(const FastArgs a)
         const uint32_t u1 = (dot4(c1, cc[2 * pp + 1], 0) << 1) + n1;
         // -cd exactly, then ONE rounding in the fma: a1 = log2(S[i][j]) - kc*cd
         const f2 ncd = f2{__uint_as_float(u0), __uint_as_float(u1)} + negC[pp];
-        const f2 lsj = *reinterpret_cast<const f2*>(&a.tab[(i * WIN + u) * 2]);
+        f2 lsj;
+        if constexpr (WIN > 21) {
+            // the device copy is read through the CONSTANT address space: never written while the kernel runs, wave-uniform
+            // address -> one s_load per pair, into the SGPR pair the argument fma takes (a plain global pointer made the
+            // compiler issue per-lane global_load_dwordx4 and hold the pairs in VGPRs: 248 instead of ~150 registers)
+            typedef const f2 __attribute__((address_space(4)))* cf2p;
+            lsj = *(cf2p)(uintptr_t)(a.tab_dev + (i * WIN + u) * 2);
+        } else {
+            lsj = *reinterpret_cast<const f2*>(&a.tab[(i * WIN + u) * 2]);
+        }
         if (CS) return pk_fma(ncd, pk_add_clamp(ncd, Tc) * kc2, lsj);   // Q1: underflowed colour factor skipped
         return pk_fma(ncd, kc2, lsj);
     };
@@ -720,6 +733,8 @@ const Variant kVariants[] = {
     K(15, 1, 16, 16, false), K(15, 2, 16, 16, false),
     K(17, 1, 16, 16, false), K(17, 2, 16, 16, false),
     K(21, 1, 16, 16, false), K(21, 2, 16, 16, false),
+    // windows 23..31: the log2(S) table no longer fits the argument block and comes from a device copy (FastArgs::tab_dev)
+    K(23, 1, 16, 16, false), K(25, 1, 16, 16, false), K(27, 1, 16, 16, false), K(29, 1, 16, 16, false), K(31, 1, 16, 16, false),
 };
 static_assert(sizeof(FastArgs) <= 4096, "FastArgs is passed by value as the kernel-argument block");
 #undef V
@@ -750,6 +765,31 @@ bool jbf_fast_supported(const JbfLaunch& l)
     return jbf_fast_default_variant(l) >= 0;
 }
 
+// log2 of the spatial table at the 2^24 scale, in the layout a variant reads: scalar kernels tab[i*W + j]; packed kernels the
+// pair (tap of p0, tap of p1) of unit u at tab[(i*W + u)*2 .. +1] (see jbf_pk_kernel).  out: W*W (scalar) / 2*W*W (packed) floats
+void jbf_fast_fill_table(int W, const float* table_host, bool packed, float* out)
+{
+    const int HALF = (W - 1) / 2;
+    auto lg = [&](int i, int j) {
+        const float sv = table_host[i * W + j];
+        return (float)(((sv == 0.0f) ? 0.0 : std::log2((double)sv)) + kScaleLog2);   // S == 0 -> factor skipped
+    };
+    if (!packed) {
+        for (int i = 0; i < W; i++)
+            for (int j = 0; j < W; j++) out[i * W + j] = lg(i, j);
+        return;
+    }
+    for (int i = 0; i < W; i++)
+        for (int u = 0; u < W; u++) {   // unit -> (tap of p0, tap of p1)
+            const int j0 = u <= HALF ? 2 * u : (u < W - 1 ? 2 * (u - HALF) + 1 : 1);
+            const int j1 = u <= HALF ? 2 * u : (u < W - 1 ? 2 * (u - HALF) - 1 : W - 2);
+            out[(i * W + u) * 2] = lg(i, j0);
+            out[(i * W + u) * 2 + 1] = lg(i, j1);
+        }
+}
+
+bool jbf_fast_needs_device_table(int window) { return window > 21; }
+
 int launch_jbf_fast(const JbfLaunch& l, int variant, const float* table_host, hipStream_t s)
 {
     if (variant < 0 || variant >= kNumVariants || kVariants[variant].window != l.window)
@@ -771,22 +811,11 @@ int launch_jbf_fast(const JbfLaunch& l, int variant, const float* table_host, hi
     a.vec4 = (l.width % 4 == 0) && ((reinterpret_cast<uintptr_t>(l.depth) & 15u) == 0) &&
              ((reinterpret_cast<uintptr_t>(l.guide) & 3u) == 0);
     KDE_STAGE(a.stage_avg = g_stage.jbf_avg; a.stage_counters = g_stage.counters; a.stage_force = g_stage.force_full_rules;)
-    const int W = l.window, HALF = (W - 1) / 2;
-    auto lg = [&](int i, int j) {
-        const float sv = table_host[i * W + j];
-        return (float)(((sv == 0.0f) ? 0.0 : std::log2((double)sv)) + kScaleLog2);   // S == 0 -> factor skipped
-    };
-    if (!kVariants[variant].packed) {
-        for (int i = 0; i < W; i++)
-            for (int j = 0; j < W; j++) a.tab[i * W + j] = lg(i, j);
+    if (jbf_fast_needs_device_table(l.window)) {
+        if (!l.log2_pk_dev) return fail(KDE_ERR_INVALID, "jbf: window %d needs the handle's device copy of the log2 table", l.window);
+        a.tab_dev = l.log2_pk_dev;
     } else {
-        for (int i = 0; i < W; i++)
-            for (int u = 0; u < W; u++) {   // unit -> (tap of p0, tap of p1): see jbf_pk_kernel
-                const int j0 = u <= HALF ? 2 * u : (u < W - 1 ? 2 * (u - HALF) + 1 : 1);
-                const int j1 = u <= HALF ? 2 * u : (u < W - 1 ? 2 * (u - HALF) - 1 : W - 2);
-                a.tab[(i * W + u) * 2] = lg(i, j0);
-                a.tab[(i * W + u) * 2 + 1] = lg(i, j1);
-            }
+        jbf_fast_fill_table(l.window, table_host, kVariants[variant].packed, a.tab);
     }
     const bool cskip = l.cd_skip <= 195075;
     return kVariants[variant].launch(l, a, cskip, s);

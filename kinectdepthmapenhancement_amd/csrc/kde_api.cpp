@@ -107,6 +107,7 @@ struct kde_jbf {
     kde_jbf_params p{};
     std::vector<float> table;       // SpatialFilter_Host
     DevBuf<float> s_eff;            // SpatialFilter_Device (zeros replaced by 1: "skip the factor")
+    DevBuf<float> log2_pk;          // windows 23..31: the packed kernels' log2(S) pairs (too large for the kernel-argument block)
     DevBuf<float> filtered;         // Filtered_Device
     DevBuf<uint8_t> smooth;         // smooth_Device
     DevBuf<float> pre_lut;          // K0 weight table
@@ -185,6 +186,13 @@ static int jbf_create_impl(kde_jbf** out, int width, int height, int max_batch, 
     if (rc == KDE_OK) rc = h->smooth.alloc(px * 3 * max_batch);
     if (rc == KDE_OK && hipMemcpy(h->s_eff.p, eff.data(), eff.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(KDE_ERR_HIP, "kde_jbf_create: table upload failed");
+    if (rc == KDE_OK && jbf_fast_needs_device_table(w)) {
+        std::vector<float> pk((size_t)2 * w * w);
+        jbf_fast_fill_table(w, h->table.data(), /*packed=*/true, pk.data());
+        rc = h->log2_pk.alloc(pk.size());
+        if (rc == KDE_OK && hipMemcpy(h->log2_pk.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(KDE_ERR_HIP, "kde_jbf_create: log2 table upload failed");
+    }
     // thresholds of the "factor == 0 -> skipped" rule (JointBilateralFilter.cu:32-33, 65-68)
     const float xz = exp_zero_threshold();
     h->color_den = 2 * (p.color_sigma * p.color_sigma);
@@ -251,6 +259,7 @@ static void jbf_fill_launch(const kde_jbf* h, JbfLaunch& a)
     a.out = nullptr;
     a.s_eff = h->s_eff.p;
     a.table_host = h->table.data();
+    a.log2_pk_dev = h->log2_pk.p;
     a.spatial_sigma = h->p.spatial_sigma;
     a.color_sigma = h->p.color_sigma;
     a.depth_sigma = h->p.depth_sigma;

@@ -126,6 +126,7 @@ struct JbfLaunch {
     float* out;                // [n][H][W]
     const float* s_eff;        // device, window^2 (zeros replaced by 1)
     const float* table_host;   // host, window^2 (calcSpatialFilter as computed)
+    const float* log2_pk_dev;  // device, 2 * window^2: the packed kernels' log2(S) pairs, windows > 21 only (jbf_fast.hip)
     float spatial_sigma, color_sigma, depth_sigma;
     float color_den, depth_den;    // 2*sigma^2 as the reference forms it (float)
     int cd_skip;               // colour factor skipped (== underflow to 0) when cd >= cd_skip
@@ -140,6 +141,8 @@ const char* jbf_fast_variant_name(int v);
 int jbf_fast_variant_window(int v);
 int jbf_fast_default_variant(const JbfLaunch& l);
 bool jbf_fast_supported(const JbfLaunch& l);
+void jbf_fast_fill_table(int window, const float* table_host, bool packed, float* out);
+bool jbf_fast_needs_device_table(int window);
 int launch_jbf_fast(const JbfLaunch& l, int variant, const float* table_host, hipStream_t s);
 int jbf_variant_count();
 const char* jbf_variant_name(int v);

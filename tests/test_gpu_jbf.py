@@ -309,7 +309,7 @@ def test_non_finite_and_huge_depth_samples(torch_cuda, F, oracle, frame):
         assert_k1_stagewise(jbf.params, big, bgr, run(-1, big), what=f"2^64 mm sample, tuned, window {win}")
 
 
-@pytest.mark.parametrize("win", [9, 11, 13, 15, 19, 21])
+@pytest.mark.parametrize("win", [9, 11, 13, 15, 19, 21, 25, 31])
 def test_rule_elision_bodies_all_match_the_oracle(torch_cuda, F, oracle, win):
     """K1's tuned kernels (windows >= 9) pick, per tile, a body without the colour and / or depth Q1 rule when the
     tile's colour / depth ranges prove the rule cannot trip.  Four quadrants force each of the four bodies: smooth,
@@ -461,30 +461,41 @@ def test_every_tuned_variant_matches_oracle(torch_cuda, F, oracle, frame, regime
 
 def test_variant_selection_errors(torch_cuda, F):
     from kinectdepthmapenhancement_amd import KdeError
-    jbf = F.JointBilateralFilter(64, 48, params(F, 23, pre=0))     # no tuned kernel for window 23: generic path
+    jbf = F.JointBilateralFilter(64, 48, params(F, 1, pre=0))      # no tuned kernel for window 1: generic path
     assert jbf.active_variant() == "generic-32x8-1px"             # ... and the handle says so (kde_jbf_active_variant)
     d = torch_cuda.full((1, 48, 64), 900.0, device="cuda")
     c = torch_cuda.zeros((1, 48, 64, 3), dtype=torch_cuda.uint8, device="cuda")
     o = torch_cuda.empty_like(d)
     jbf.filter_batch(d, c, o)
-    assert torch_cuda.allclose(o, d, rtol=1e-5)                    # (a float32 mean of 529 equal taps)
-    jbf.set_variant(1)                                             # a window-5 kernel cannot serve window 23
+    assert torch_cuda.equal(o, d)                                  # (one tap: the pixel itself)
+    jbf.set_variant(1)                                             # a window-5 kernel cannot serve window 1
     with pytest.raises(KdeError):
         jbf.filter_batch(d, c, o)
     with pytest.raises(KdeError):
         jbf.set_variant(10 ** 6)
 
 
-def test_tuned_kernels_serve_every_window_up_to_21(torch_cuda, F):
+def test_tuned_kernels_serve_every_window(torch_cuda, F, oracle, frame):
     """the ABI takes any odd window <= 31 (the reference's window_size is a run-time argument,
-    JointBilateralFilter.cu:10,18-19); windows 3..21 select a tuned packed kernel, wider ones, zero sigmas and exotic colour
-    sigmas the generic one -- and kde_jbf_active_variant tells which"""
+    JointBilateralFilter.cu:10,18-19); every window from 3 to 31 selects a tuned packed kernel (23..31 read their log2(S)
+    table from a device copy: it no longer fits the kernel-argument block), window 1, zero sigmas and exotic colour sigmas
+    the generic one -- and kde_jbf_active_variant tells which"""
     for win in range(1, 32, 2):
         name = F.JointBilateralFilter(64, 48, params(F, win, 3.0, 7.65, 20.0, pre=0)).active_variant()
-        if 3 <= win <= 21:
+        if win >= 3:
             assert name.startswith(f"w{win}-pk"), (win, name)
         else:
             assert name == "generic-32x8-1px", (win, name)
+    # the wide windows against the oracle through the default path (Process with pre-smoothing, batch of 2)
+    bgr, depth = frame(5, 96, 72)
+    for win in (23, 27, 31):
+        p = params(F, win, 6.0, 20.0, 30.0)
+        jbf = F.JointBilateralFilter(96, 72, p, max_batch=2)
+        out = host(jbf.process_batch(dev(torch_cuda, np.stack([depth, depth[::-1].copy()])), dev(torch_cuda, np.stack([bgr, bgr[::-1].copy()]))))
+        smooth = host(jbf.getSmoothImage_Device(2))
+        assert np.array_equal(smooth[0], oracle.cv_bilateral(bgr, 5, 30.0, 30.0))
+        assert_k1_stagewise(p, depth, smooth[0], out[0], what=f"window {win} through the device table")
+        assert_k1_stagewise(p, depth[::-1].copy(), smooth[1], out[1], what=f"window {win}, second frame of the batch")
     assert F.JointBilateralFilter(64, 48, params(F, 11, 3.0, 0.0, 20.0, pre=0)).active_variant() == "generic-32x8-1px"      # colour term off
     j = F.JointBilateralFilter(64, 48, params(F, 11, 3.0, 7.65, 20.0, pre=0))
     j.set_variant(0)

@@ -179,7 +179,7 @@ micro_pmc)
   ;;
 windows)
   # every tuned window next to the generic kernel (one pixel per thread): tools/sweep_jbf.py, 64 x 640x480
-  for W in 3 5 7 9 11 13 15 17 19 21; do
+  for W in 3 5 7 9 11 13 15 17 19 21 23 25 27 29 31; do
     python3 tools/sweep_jbf.py --width 640 --height 480 --frames 64 --window $W --with-generic --iters 3 --rounds 3
   done > "$OUT/sweep_k1_windows.log" 2> "$OUT/sweep_windows.err"
   cat "$OUT/sweep_k1_windows.log"

@@ -66,7 +66,7 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
         w, h = int(rng.integers(1, 200)), int(rng.integers(1, 150))
         try:
             if kind == "k1":
-                win = int(rng.choice([1, 3, 5, 5, 7, 9, 11, 11, 13, 15, 17, 19, 21, 31]))
+                win = int(rng.choice([1, 3, 5, 5, 7, 9, 11, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31]))
                 ss = float(rng.choice([0.5, 1.0, 3.0, 30.0, 70.0]))
                 cs = float(rng.choice([0.0, 2.0, 7.65, 20.0, 50.0, 400.0]))
                 ds = float(rng.choice([0.0, 5.0, 20.0, 70.0, 1000.0]))
