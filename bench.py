@@ -404,6 +404,8 @@ def main():
     local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} != --gpus {args.gpus}")
+    if 0 < args.total_frames < world:        # the same test on every rank, before any collective: all ranks leave together
+        raise SystemExit(f"--total-frames {args.total_frames} leaves some of the {world} ranks without a frame")
     if args.share_device and args.backend == "nccl" and world > 1 and not args.force_rccl_failure:
         raise SystemExit("--share-device needs --backend gloo (RCCL wants one device per rank)")
     if not args.dry_run:

@@ -87,12 +87,15 @@ int main()
     expect(throws_invalid([&] { jbf.Process(d_depth, padded); }) && throws_invalid([&] { jbf.Process(d_depth, wrong); }), "JBF rejects padded / wrong-size images");
     expect(throws_invalid([&] { mrf.Process(d_depth, padded); }), "MRF rejects a padded image");
     {   // which kernel an object runs (kde_jbf_active_variant): the reference constants select a tuned window-5 kernel, a
-        // window of 23 the generic one
-        kde_jbf_params wide;
+        // window of 31 a tuned one too, a zero colour sigma (term off) the generic kernel
+        kde_jbf_params wide, nocolour;
         kde_jbf_default_params(&wide);
-        wide.window_size = 23;
-        JointBilateralFilter jbf23(W, H, wide);
-        expect(std::strncmp(jbf.activeKernel(), "w5-pk", 5) == 0 && std::strcmp(jbf23.activeKernel(), "generic-32x8-1px") == 0,
+        wide.window_size = 31;
+        kde_jbf_default_params(&nocolour);
+        nocolour.color_sigma = 0.0f;
+        JointBilateralFilter jbf31(W, H, wide), jbf0(W, H, nocolour);
+        expect(std::strncmp(jbf.activeKernel(), "w5-pk", 5) == 0 && std::strncmp(jbf31.activeKernel(), "w31-pk", 6) == 0 &&
+                   std::strcmp(jbf0.activeKernel(), "generic-32x8-1px") == 0,
                "activeKernel() names the tuned / generic kernel");
     }
     expect(throws_invalid([&] { dasp.Segmentation(padded, d_pts, 200.f, 40.f, 0.f, 1); }) &&
