@@ -261,13 +261,19 @@ def make_inputs(synth, torch, first_seed, n, w, h, distinct):
     return torch.from_numpy(bgr).cuda(), torch.from_numpy(depth).cuda()
 
 
-def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier, wakeup_ms=0.0, split=False):
+def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier, wakeup_ms=0.0, split=False, keep_busy_ms=0.0):
     """device wake-up, W untimed + exactly K timed steps.
     split=False: a step is ONE boundary call, kde_jbf_process_batch (JointBilateralFilter::Process on the batch), with an event
                  before and after it;
     split=True : the two launches that call makes, issued separately (kde_jbf_presmooth_batch = K0, kde_jbf_filter_batch = K1)
                  with an event between them: the per-kernel times `roofline` reads.
-    returns (wall seconds of the K steps, per-step ms list [K0 + K1 when split], K0 ms list | None, K1 ms list | None, wake-up steps)."""
+    keep_busy_ms: untimed steps worth that much GPU time are enqueued right before the barrier that precedes the timed region,
+                 so that the GPU is still working while the host waits for the other ranks: the synchronize() that follows the
+                 barrier then returns microseconds before the first timed launch.  Without it the GPU idles for the length of
+                 the barrier (milliseconds over TCP or RCCL), drops its clock, and the first timed steps measure the ramp
+                 (1.45 ms instead of 1.19: tools/exp_dist_overhead.sh).  0 = none (the from-idle leg).
+    returns (wall seconds of the K steps, per-step ms list [K0 + K1 when split], K0 ms list | None, K1 ms list | None,
+             wake-up steps, untimed steps enqueued before the barrier)."""
     def step(evs=None):
         if evs:
             evs[0].record()
@@ -281,20 +287,32 @@ def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier, wa
         if evs:
             evs[-1].record()
 
-    barrier()                                       # also brings the RCCL communicator up before anything is timed
+    barrier()
     # Device wake-up, before the W warm-up steps and outside every timed region: an idle MI355X sits at its lowest
     # clock level and needs ~100 ms of load to reach the clock it then holds; with W = 5 (6.5 ms) the K timed steps
     # would otherwise measure that ramp (first step 1.27 ms, last 1.11 ms) instead of the kernel.
-    woke = 0
+    woke, est_ms = 0, None
     t_w = time.perf_counter()
     while wakeup_ms > 0 and (time.perf_counter() - t_w) * 1e3 < wakeup_ms:
         for _ in range(10):
             step()
         torch.cuda.synchronize()
         woke += 10
+    if woke:
+        est_ms = (time.perf_counter() - t_w) * 1e3 / woke
+    elif keep_busy_ms > 0:                          # no wake-up loop to take the step time from: one probe step
+        t_p = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        est_ms = (time.perf_counter() - t_p) * 1e3
     for _ in range(warmup):
         step()
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3 if split else 2)] for _ in range(steps)]
+    filler = 0
+    if keep_busy_ms > 0:
+        filler = max(2, min(400, int(keep_busy_ms / max(est_ms, 0.02)) + 1))
+        for _ in range(filler):
+            step()                                  # untimed: keeps the GPU busy while the host is in the barrier
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -306,7 +324,7 @@ def time_steps(torch, jbf, depth, color, smooth, out, steps, warmup, barrier, wa
     step_ms = [e[0].elapsed_time(e[-1]) for e in evs]
     k0 = [e[0].elapsed_time(e[1]) for e in evs] if split else None
     k1 = [e[1].elapsed_time(e[2]) for e in evs] if split else None
-    return dt, step_ms, k0, k1, woke
+    return dt, step_ms, k0, k1, woke, filler
 
 
 def usable_cores():
@@ -483,17 +501,20 @@ def main():
     # from an idle GPU first (the W + K contract by itself), then at the clock the GPU holds under load (the headline)
     idle = None
     if args.wakeup_ms > 0 and not args.no_idle_leg:
-        dt_i, st_i, _, _, _ = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, 0.0)
+        dt_i, st_i, _, _, _, _ = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, 0.0)
         dt_i = comm.allreduce_max(dt_i)
         idle = {"value": total_frames * W * H * args.steps / dt_i / 1e6, "ms_per_step": dt_i / args.steps * 1e3,
                 "step_gpu_ms_first_median_last": [float(st_i[0]), float(np.median(st_i)), float(st_i[-1])],
                 "note": "same W warm-up + K timed steps started from an idle GPU (lowest clock level), measured before the headline"}
     # ---- the headline: K x kde_jbf_process_batch --------------------------------------------------------------------
-    dt, step_ms, _, _, woke = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, args.wakeup_ms)
-    # ---- the same K steps as two separate launches, right behind it (no idle gap: the clock stays where it is), into
-    # buffers of their own: the per-kernel times the roofline object reads ------------------------------------------
-    out2 = torch.empty_like(out)
-    dt_s, _, k0_ms, k1_ms, _ = time_steps(torch, jbf, depth, color, smooth, out2, args.steps, args.warmup, barrier, 0.0, split=True)
+    out2 = torch.empty_like(out)            # (allocated before anything is timed: no allocation gap between the two legs)
+    busy = 30.0 if args.wakeup_ms > 0 else 0.0      # --wakeup-ms 0 = the bare W + K contract, as in the from-idle leg
+    dt, step_ms, _, _, woke, filler = time_steps(torch, jbf, depth, color, smooth, out, args.steps, args.warmup, barrier, args.wakeup_ms,
+                                                 keep_busy_ms=busy)
+    # ---- the same K steps as two separate launches, right behind it, into buffers of their own: the per-kernel times the
+    # roofline object reads.  (A short wake-up of its own: the barriers between the legs idle the GPU for a moment) ----
+    dt_s, _, k0_ms, k1_ms, _, _ = time_steps(torch, jbf, depth, color, smooth, out2, args.steps, args.warmup, barrier,
+                                             min(args.wakeup_ms, 50.0), split=True, keep_busy_ms=busy)
     dt, dt_s = comm.allreduce_max(dt), comm.allreduce_max(dt_s)
     split_same = bool(torch.equal(out2, out))
     del out2
@@ -529,6 +550,7 @@ def main():
             "value": value,
             "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "wakeup_steps_before_warmup": woke,
+            "untimed_steps_enqueued_before_the_start_barrier": filler,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -544,6 +566,7 @@ def main():
             "ranks_seen": ranks_seen, "devices": devices, "distinct_devices": len({d.get("pci_bus_id") for d in devices}),
             "rccl": rccl, "replicas_only": replicas_only,
             "boundary_vs_split": {"step_gpu_ms_mean": float(np.mean(step_ms)), "step_gpu_ms_median": float(np.median(step_ms)),
+                                  "step_gpu_ms_all": [round(float(v), 4) for v in step_ms],
                                   "split_leg_ms_per_step": dt_s / args.steps * 1e3, "split_leg_value": total_frames * W * H * args.steps / dt_s / 1e6,
                                   "value_over_split_leg_value": value / (total_frames * W * H * args.steps / dt_s / 1e6),
                                   "k0_plus_k1_ms": float(np.mean(k0_ms) + np.mean(k1_ms)), "outputs_bit_identical": split_same},
@@ -589,8 +612,10 @@ def shard_legs(torch, filters, synth, args, barrier):
     if args.variant >= 0:
         jbf.set_variant(args.variant)
     steps = max(3, min(args.steps, 10))
-    dt, _, _, _, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 2, barrier)                 # K x the boundary call
-    _, _, k0, k1, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 1, barrier, split=True)    # its two launches
+    busy = 40.0 if args.wakeup_ms > 0 else 0.0
+    dt, _, _, _, _, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 2, barrier, min(args.wakeup_ms, 100.0),
+                                   keep_busy_ms=busy)                                                   # K x the boundary call
+    _, _, k0, k1, _, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 1, barrier, split=True, keep_busy_ms=busy)  # its two launches
     out["fhd_w19_config3"] = {"workload": f"JointBilateralFilter::Process (K0 + K1) on {n} x {w}x{h} per GPU, window {window}, sigma 3/7.65/20 "
                                           "(BASELINE config 3 as SURVEY 8(d) sizes it: 730 MB of algorithmic traffic per launch)",
                               "frames": n, "width": w, "height": h, "window": window, "px": n * w * h, "steps": steps, "dt_s": dt,
@@ -656,8 +681,8 @@ def single_gpu_extras(torch, filters, synth, args):
         if args.variant >= 0:
             jbf.set_variant(args.variant)
         steps = max(3, min(args.steps, 10))
-        dt, _, _, _, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 2, lambda: None)
-        _, _, k0, k1, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 1, lambda: None, split=True)
+        dt, _, _, _, _, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 2, lambda: None)
+        _, _, k0, k1, _, _ = time_steps(torch, jbf, depth, color, smooth, res, steps, 1, lambda: None, split=True)
         px = n * w * h
         k1m = float(np.mean(k1))
         names = filters.JointBilateralFilter.variants()

@@ -106,8 +106,8 @@ class ShardComm:
     A gloo group over 127.0.0.1 is always created first: it is the rendezvous, it carries the agreement on whether RCCL is
     usable, and it is what the run falls back to.  With backend "nccl" every rank then tries to bring up an RCCL group on
     its own device (`new_group(backend="nccl", device_id=...)` + one all-reduce as a smoke test) INSIDE THE SAME PROCESS;
-    the ranks exchange their outcome over gloo, and RCCL is used for the parameter broadcast, the barriers and the report's
-    reductions only if it came up on EVERY rank.  Otherwise nothing is re-executed or restarted (a process that has touched
+    the ranks exchange their outcome over gloo, and RCCL is used for the parameter broadcast and the report's reductions
+    only if it came up on EVERY rank (the barriers around timed regions stay host-side, see barrier()).  Otherwise nothing is re-executed or restarted (a process that has touched
     the GPU must not be replaced): every rank computes the parameter block itself ("replicas only"), the blocks are
     compared over gloo, `rccl_error` holds the first exception text and the caller flags the run.
 
@@ -164,11 +164,11 @@ class ShardComm:
         return torch.device("cuda", self.local_rank) if self.group is not None else torch.device("cpu")
 
     def barrier(self) -> None:
-        if not self.active:
-            return
-        if self.group is not None:
-            dist.barrier(group=self.group, device_ids=[self.local_rank])
-        else:
+        """host-side rendezvous of the ranks (always over the gloo group).  The barriers that bracket a timed region must not
+        touch the GPU: an RCCL barrier is a kernel plus a host wait of a few milliseconds, long enough for an MI355X to drop
+        its clock -- measured: the first timed steps right behind it ran 22 % slow and the headline lost 10 %
+        (tools/exp_dist_overhead.sh).  RCCL carries the parameter broadcast and the reductions, where latency is irrelevant."""
+        if self.active:
             dist.barrier()
 
     def broadcast_params(self, block: np.ndarray, src: int = 0) -> np.ndarray:
