@@ -19,10 +19,10 @@ One JSON line is printed by rank 0; besides the contract fields it carries
                  (4 B depth read + 3 B packed-BGR guide read + 4 B filtered write) x pixels per launch
                  / its average launch duration, measured with HIP events on the launch stream
                  (the split leg).  K1 is instruction-issue bound, not HBM-bound, so the object also carries
-                 `valu.mix_ceiling`: the time the kernel's VALU instructions alone need -- its own mix priced with the
-                 MEASURED issue cost of every opcode (tools/valu_microbench -> profiles/valu_costs.json; tools/valu_mix.py
-                 on the committed PMC counts of exactly this code, profiles/pmc_bench.json, matched by a hash of the kernel
-                 sources) -- over the launch time measured live; and `fhd_w19`: the same figures for the pass north_star's
+                 `valu.mix_ceiling`: the shader cycles the kernel's VALU instructions alone need -- its own mix, each opcode at
+                 the issue rate of its MEASURED class (2 / 4 / 8 cycles: tools/valu_microbench -> profiles/valu_costs.json;
+                 tools/valu_mix.py on the committed PMC counts of exactly this code, profiles/pmc_bench.json, matched by a
+                 hash of the kernel sources) -- over the cycles of the same profiled launch; and `fhd_w19`: the same figures for the pass north_star's
                  roofline target names (32 x 1920x1080, window 19; BASELINE config 3), run by every rank, with
                  `k1_mpix_s_noelide` = its data-independent floor;
   verified     — frame 0 of the TIMED output checked after the timed region, stage by stage (oracle.stage_check): the
@@ -33,7 +33,14 @@ One JSON line is printed by rank 0; besides the contract fields it carries
                  timed on this host on a bounded sample of the same workload (OpenMP over rows), and
   cpu_baseline_1t — the same on one thread (SURVEY 8d);
   from_idle    — the same W + K steps measured first, from an idle GPU (no wake-up load): what the fixed W = 5 / K = 20
-                 contract gives by itself; `value` is the steady-clock figure measured right after.
+                 contract gives by itself; `value` is the steady-clock figure measured right after;
+  ranks_seen / devices / rccl / replicas_only — who took part (an all-reduce of 1; rank, pid, arch and PCI address of every
+                 rank's GPU) and over what: RCCL when it came up on every rank, else the in-process gloo fallback, flagged;
+  also         — side legs: at every N the config-5 chain on 64 x 640x480 per GPU through the batched entry points (run by
+                 every rank, reduced like the headline); at N = 1 the reference constants, K1's dependence on content at
+                 windows 11 and 19, this chip's copy ceiling, the single-frame chain, the feeder.
+The barriers around timed regions are host-side (gloo) and the GPU is kept busy through the start barrier (time_steps):
+an idle gap of a few milliseconds in front of the K timed steps makes an MI355X drop its clock.
 """
 import argparse
 import json
