@@ -162,6 +162,30 @@ struct CalcDivs {          // divisions of the assignment step by multiplication
     FastDiv24 wx, wy, cols;
 };
 
+// "take = d < best; best = take ? d : best; label = take ? id : label" compiles to one v_cmp and TWO back-to-back
+// v_cndmask_b32 in the VOP2 encoding (condition implicitly in VCC) -- and on gfx950 the second of two adjacent VOP2 v_cndmask
+// stalls the SIMD for ~20 cycles (tools/valu_microbench: "1 v_cmp + 2 v_cndmask (vcc)" 3.2-6.8 ns per instruction against
+// 1.3 with one other VALU instruction between them and 1.7 in the VOP3 encoding; profiles/r04_valu_microbench_vcc.txt).
+// The argmin update therefore keeps its condition in an SGPR pair and selects with the VOP3 form: same results, no stall.
+__device__ __forceinline__ uint64_t lt_mask(float x, float y)
+{
+    uint64_t m;
+    asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "v"(y));
+    return m;
+}
+__device__ __forceinline__ float sel_f(uint64_t m, float a, float b)       // m ? a : b
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ int sel_i(uint64_t m, int a, int b)
+{
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+
 template <int NS, bool USE_LDS, bool FIRST>
 __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
                                                      const kde_float3* __restrict__ pts, CalcSets<NS> sets, float win2,
@@ -294,9 +318,9 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
                     if (n < lo || n > hi) continue;
                     const float d = (!INNER && id < 0) ? cur.d : own_d[n];        // .cu:221-224 outside the grid
                     const int l = (!INNER && id < 0) ? cur.l : id;
-                    const bool take = d < best[n];
-                    best[n] = take ? d : best[n];
-                    bl[n] = take ? l : bl[n];
+                    const uint64_t take = lt_mask(d, best[n]);
+                    best[n] = sel_f(take, d, best[n]);
+                    bl[n] = sel_i(take, l, bl[n]);
                 }
                 continue;
             }
@@ -320,9 +344,9 @@ __global__ __launch_bounds__(256) void calc_ld_kernel(DaspGeom g, const uint8_t*
                 if (n < lo || n > hi) continue;
                 const CalcSet& cs = sets.s[n];
                 const float d = cdv * cs.kc + sdv * cs.ks + ddv * cs.kd;          // .cu:218
-                const bool take = d < best[n];
-                best[n] = take ? d : best[n];
-                bl[n] = take ? id : bl[n];
+                const uint64_t take = lt_mask(d, best[n]);
+                best[n] = sel_f(take, d, best[n]);
+                bl[n] = sel_i(take, id, bl[n]);
             }
         }
 #pragma unroll

@@ -99,6 +99,47 @@ constexpr int kUnroll = 32;    // instructions (or instruction groups) per loop 
     X(CMP_CNDMASK, "v_cmp_lt_f32 + v_cndmask_b32 (per instruction)", 2,                                                           \
       asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(c0) : "vcc");                                               \
       asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[J]) : "v"(c0) : "vcc");)                                             \
+    X(CMP_2CND, "1 v_cmp_lt_f32 (vcc) + 2 v_cndmask_b32 (vcc)", 3,                                                                 \
+      asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(c0) : "vcc");                                               \
+      asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[J]) : "v"(c0) : "vcc");                                              \
+      asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[K2]) : "v"(c1) : "vcc");)                                            \
+    X(CMP_4CND, "1 v_cmp_lt_f32 (vcc) + 4 v_cndmask_b32 (vcc)", 5,                                                                 \
+      asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(c0) : "vcc");                                               \
+      asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[J]) : "v"(c0) : "vcc");                                              \
+      asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[K2]) : "v"(c1) : "vcc");                                             \
+      asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[(i + 3) & 7]) : "v"(c0) : "vcc");                                    \
+      asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[(i + 4) & 7]) : "v"(c1) : "vcc");)                                   \
+    X(CMP64_2CND, "1 v_cmp_lt_f32_e64 (sgpr pair) + 2 v_cndmask_b32_e64 (same pair)", 3,                                            \
+      asm volatile("v_cmp_lt_f32_e64 s[10:11], %0, %1" : : "v"(a[i]), "v"(c0) : "s10", "s11");                                   \
+      asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a[J]) : "v"(c0) : "s10", "s11");                              \
+      asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a[K2]) : "v"(c1) : "s10", "s11");)                            \
+    X(CMP_MUL_CND, "1 v_cmp_lt_f32 (vcc) + 2 v_mul_f32 + 1 v_cndmask_b32 (vcc)", 4,                                                 \
+      asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(c0) : "vcc");                                               \
+      asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[J]) : "v"(c0));                                                               \
+      asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[K2]) : "v"(c0));                                                              \
+      asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[(i + 3) & 7]) : "v"(c0) : "vcc");)                                   \
+    X(MIX_2C_RUN, "4 v_mul_f32 + 1 v_pk_fma_f32", 5,                                                                               \
+      asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));                                                               \
+      asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[J]) : "v"(c0));                                                               \
+      asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[K2]) : "v"(c0));                                                              \
+      asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[(i + 3) & 7]) : "v"(c0));                                                     \
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pc0), "v"(pc1));)                                            \
+    X(CMP_CND_MUL_CND, "1 v_cmp_lt_f32 (vcc) + v_cndmask (vcc) + v_mul_f32 + v_cndmask (vcc)", 4,                                  \
+      asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(c0) : "vcc");                                               \
+      asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[J]) : "v"(c0) : "vcc");                                              \
+      asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[K2]) : "v"(c0));                                                              \
+      asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[(i + 3) & 7]) : "v"(c1) : "vcc");)                                   \
+    X(CMP_2CND_VOP3, "1 v_cmp_lt_f32 (vcc) + 2 v_cndmask_b32_e64 (vcc as explicit operand)", 3,                                     \
+      asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(c0) : "vcc");                                               \
+      asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a[J]) : "v"(c0) : "vcc");                                          \
+      asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a[K2]) : "v"(c1) : "vcc");)                                        \
+    X(CMP_2CND_DIFFSRC, "1 v_cmp_lt_f32 (vcc) + 2 v_cndmask_b32 (vcc), distinct dst and sources", 3,                                \
+      asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(c0) : "vcc");                                               \
+      asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[J]) : "v"(c0), "v"(c1) : "vcc");                                     \
+      asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[K2]) : "v"(c1), "v"(c0) : "vcc");)                                   \
+    X(ADDC_CHAIN, "1 v_add_co_u32 (vcc) + 1 v_addc_co_u32 (vcc)", 2,                                                                \
+      asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(u[i]) : "v"(u[J]) : "vcc");                                             \
+      asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(u[K2]) : "v"(u[(i + 3) & 7]) : "vcc");)                           \
     X(READLANE, "v_readlane_b32", 1, asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sx) : "v"(u[i]));)                           \
     X(READFIRST, "v_readfirstlane_b32", 1, asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sx) : "v"(u[i]));)                  \
     X(MBCNT, "v_mbcnt_lo_u32_b32", 1, asm volatile("v_mbcnt_lo_u32_b32 %0, -1, %0" : "+v"(u[i]));)                              \
