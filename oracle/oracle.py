@@ -108,9 +108,14 @@ def parity_check(got, ref, env=None, rtol=1e-4):
     with np.errstate(invalid="ignore", divide="ignore"):
         rel = np.where((ref != 0) & ~nan_ref & ~nan_got, np.abs(g64 - r64) / np.abs(r64), 0.0)
     strict = ~flagged
+    # ZERO_OK without BAND / COND: the envelope's binary64 evaluation found NO weight where the float32 restatement still
+    # holds sub-unit survivors (exact weights below 2^-150 that round up to one denormal unit: a hole whose taps all lie the
+    # depth-factor underflow distance away) -- 0 is admissible there next to the float32 value, nothing else is
+    # (tools/stress_parity.py seed 603 case 17338: window 3, sigma 1 / 2 / 70; tests/golden/k1_zero_ok_without_band.npz)
+    zero_adm = np.zeros(ref.shape, bool) if env is None else (((env.flags.reshape(ref.shape) & Env.ZERO_OK) != 0) & (got == 0) & ~nan_got)
     bad_nan = strict & (nan_ref != nan_got)
-    bad_zero = strict & ~nan_ref & ~nan_got & ((ref == 0) != (got == 0))
-    bad_rel = strict & (rel > rtol)
+    bad_zero = strict & ~nan_ref & ~nan_got & ((ref == 0) != (got == 0)) & ~zero_adm
+    bad_rel = strict & (rel > rtol) & ~zero_adm
     bad_env = np.zeros(ref.shape, bool)
     band = cond = 0
     if env is not None and flagged.any():

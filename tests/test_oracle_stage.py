@@ -227,3 +227,30 @@ def test_k1_stage_pass2_weights_below_the_underflow_point_that_survive(oracle):
     far = out.copy()
     far[y, x] = 5000.0                     # ... but not a value no tap of the window can produce
     assert oracle.stage_check(far, st)["bad"][y, x]
+
+
+def test_envelope_cross_check_admits_zero_where_binary64_finds_no_weight(oracle):
+    """tools/stress_parity.py seed 603 case 17338 (tests/golden/k1_zero_ok_without_band.npz; window 3, sigma 1 / 2 / 70, the first
+    stress case that hit the tuned window-3 kernel in this regime).  A hole whose valid taps all differ in colour (colour factor
+    underflowed: skipped) and lie ~1006 mm from the first-pass average: every pass-2 weight S exp(-103.3) is 0.4 .. 0.8 denormal
+    units.  The float32 restatement keeps the taps whose product rounds UP to one unit and returns 1833.5; the exact weights are
+    all below 2^-150, so binary64 -- and the tuned kernel, which flushes at an exact 2^-150 -- say "no weight": 0.  The stage-wise
+    check has admitted both since r03 (GRID + ZERO_OK); the float32-envelope cross-check flagged the pixel ZERO_OK but, having
+    neither BAND nor COND, compared it strictly.  Now 0 is admissible wherever the envelope says so -- and nothing else is."""
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "k1_zero_ok_without_band.npz"))
+    win, ss, cs, ds = z["params"]
+    y, x = (int(v) for v in z["pixel"])
+    ref, env = oracle.jbf_kernel(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds), return_ill=True)
+    assert ref[y, x] == 1833.5 and z["got"][y, x] == 0.0 and z["depth"][y, x] == 0.0
+    assert env.flags[y, x] & oracle.Env.ZERO_OK and not env.flagged[y, x]
+    st = oracle.jbf_stage(z["depth"], z["bgr"], int(win), float(ss), float(cs), float(ds))
+    assert st.flags[y, x] & oracle.Stage.GRID and st.flags[y, x] & oracle.Stage.ZERO_OK and st.fin64[y, x] == 0.0
+    assert not oracle.parity_check(z["got"], ref, env)["bad"].any()             # the GPU's output of that case: passes now
+    assert not oracle.parity_check(ref, ref, env)["bad"].any()                  # ... and so does the float32 value itself
+    other = ref.copy()
+    other[y, x] = 1500.0                                                        # any third value is still rejected
+    assert oracle.parity_check(other, ref, env)["bad"][y, x]
+    st_zero = oracle.stage_check(z["got"], st)
+    assert not st_zero["bad"][y, x]

@@ -165,6 +165,42 @@ micro)
   tools/valu_microbench > "$OUT/valu_microbench.txt" 2>&1
   python3 tools/valu_costs.py "$OUT/valu_microbench.txt" --table
   ;;
+pmc_k8)
+  # K8 (analyzeClusters) against the L1 / texture-address path: is the per-lane request rate the floor?
+  timeout -k 10 400 rocprofv3 --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE \
+      --output-format csv -d "$OUT/pmc_k8/ta" -o ta -- python3 tools/bench_spdsr.py --wakeup-ms 0 > "$OUT/pmc_k8.ta.log" 2>&1
+  timeout -k 10 400 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum GRBM_GUI_ACTIVE \
+      --output-format csv -d "$OUT/pmc_k8/tcp" -o tcp -- python3 tools/bench_spdsr.py --wakeup-ms 0 > "$OUT/pmc_k8.tcp.log" 2>&1
+  find "$OUT/pmc_k8" -name "*.csv" ! -name "*counter_collection.csv" -delete
+  python3 - "$OUT" <<'PY'
+import csv, glob, json, sys
+from collections import defaultdict
+out = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(list))
+for path in glob.glob(f"{out}/pmc_k8/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(path, newline="")):
+        name = row["Kernel_Name"]
+        for key in ("analyze_clusters", "calc_ld_kernel", "mrf_sweep", "enhance7", "edge_fused"):
+            if key in name:
+                acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                acc[key]["duration_ns"].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+res = {}
+for k, c in acc.items():
+    m = {n: sum(v) / len(v) for n, v in c.items()}
+    cyc = m.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+    d = dict(m)
+    if cyc > 0:
+        d["cycles"] = cyc
+        for n in ("TA_TA_BUSY_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum"):
+            if n in m:
+                d[n.replace("_sum", "") + "_frac_of_256_CU_cycles"] = m[n] / (256.0 * cyc)
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in m:
+            d["cache_line_accesses_per_CU_per_cycle"] = m["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256.0 * cyc)
+    res[k] = d
+json.dump(res, open(f"{out}/pmc_k8.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
+  ;;
 micro_pmc)
   # which SQ_INSTS_VALU_* class counter books which opcode (one kernel of the micro-benchmark = one opcode)
   # ... and the issue cost of every opcode in shader CYCLES (GRBM_GUI_ACTIVE / 8 over SQ_INSTS_VALU / 1024 SIMDs): independent of
