@@ -167,10 +167,12 @@ micro)
   ;;
 pmc_k8)
   # K8 (analyzeClusters) against the L1 / texture-address path: is the per-lane request rate the floor?
-  timeout -k 10 400 rocprofv3 --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE \
-      --output-format csv -d "$OUT/pmc_k8/ta" -o ta -- python3 tools/bench_spdsr.py --wakeup-ms 0 > "$OUT/pmc_k8.ta.log" 2>&1
-  timeout -k 10 400 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum GRBM_GUI_ACTIVE \
-      --output-format csv -d "$OUT/pmc_k8/tcp" -o tcp -- python3 tools/bench_spdsr.py --wakeup-ms 0 > "$OUT/pmc_k8.tcp.log" 2>&1
+  # (the TA and TCP blocks take two counters per pass)
+  k8pass() { local tag=$1; shift; timeout -k 5 120 rocprofv3 --pmc "$@" GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_k8/$tag" -o $tag -- python3 tools/bench_spdsr.py --wakeup-ms 0 > "$OUT/pmc_k8.$tag.log" 2>&1 || echo "pmc_k8 pass $tag failed"; }
+  k8pass ta1 TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum
+  k8pass ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
+  k8pass tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum
+  k8pass tcp2 TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
   find "$OUT/pmc_k8" -name "*.csv" ! -name "*counter_collection.csv" -delete
   python3 - "$OUT" <<'PY'
 import csv, glob, json, sys
