@@ -72,8 +72,8 @@ def broadcast_params(block: np.ndarray, device: Optional[torch.device] = None, s
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" \
             else torch.device("cpu")
-    t = torch.from_numpy(np.ascontiguousarray(block, np.float64)).to(device)
-    dist.broadcast(t, src=src, group=group)
+    t = torch.from_numpy(np.array(block, np.float64, copy=True)).to(device)     # a copy: the caller's block must stay its own
+    dist.broadcast(t, src=src, group=group)                                      # (on the CPU .to() would alias it)
     return t.cpu().numpy()
 
 

@@ -72,3 +72,38 @@ def test_world_size_2_gloo_broadcast_and_disjoint_shards():
     assert (ret[0][4], ret[0][5]) == (0, 4) and (ret[1][4], ret[1][5]) == (4, 3)
     assert ret[0][6] == [1.0] * 7          # every frame processed exactly once across the ranks
     assert ret[0][7] == ret[1][7] == 2.0   # max over ranks
+
+
+def _comm_worker(rank, world, port, force_fail, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    comm = sharding.ShardComm("nccl", local_rank=rank, use_gpu=False, force_rccl_failure=force_fail)
+    try:
+        blk = np.full(sharding.BLOCK_LEN, float(rank + 1))          # every rank forms "its own" block
+        got = comm.broadcast_params(blk)                            # rank 0's arrives everywhere
+        differs = int(comm.allreduce_sum([0.0 if np.array_equal(blk, got) else 1.0])[0])
+        comm.barrier()
+        ret[rank] = (comm.active, comm.replicas_only, comm.backend_used, comm.rccl_error, float(got[0]), differs,
+                     comm.allreduce_max(float(rank)), comm.gather_objects({"rank": rank}))
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("force_fail", [False, True])
+def test_shardcomm_gloo_rendezvous_and_in_process_fallback(force_fail):
+    """sharding.ShardComm on two CPU ranks: the gloo group is the rendezvous; without a GPU RCCL is not attempted (dry run), with
+    a forced RCCL failure every rank agrees on the fallback -- same processes, gloo for the broadcast / reductions, `replicas_only`
+    and the first rank's exception text on EVERY rank (SURVEY 8e "Fallback")."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_comm_worker, args=(2, port, force_fail, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        active, replicas, backend, err, first, differs, tmax, objs = ret[r]
+        assert active and first == 1.0 and differs == 1 and tmax == 1.0            # rank 0's block; exactly one rank's own differs
+        assert objs == [{"rank": 0}, {"rank": 1}]
+        if force_fail:
+            assert replicas and backend.startswith("gloo (RCCL unavailable)") and err.startswith("rank 0: RuntimeError") and "+1 more" in err
+        else:
+            assert not replicas and err is None and backend.startswith("gloo (dry run")
