@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """ISA-level account of a kernel's inner loops: compiles one .hip file to gfx950 assembly (device side only), finds the
 loops of the requested kernel (a label that a later s_cbranch jumps back to) and prints, per loop, the instruction
-histogram by class and the issue slots it costs under the model DESIGN.md / bench.py's roofline.valu use (one 4-cycle
-slot per VALU instruction, two for a transcendental), next to the costs measured by tools/valu_microbench.
+histogram by class and the nominal issue slots of r01-r03's model (one 4-cycle slot per VALU instruction, two for a
+transcendental).  Since r04 the ceiling DESIGN.md / bench.py quote is NOT this model: tools/valu_mix.py prices the same
+histogram with the issue rate of every opcode's measured class (2 / 4 / 8 cycles, profiles/valu_costs.json) and scales it to
+the hardware's instruction-class counters; this tool stays for the per-loop view (instructions per unit, LDS / SALU / nop share).
 
     python3 tools/isa_slots.py --file jbf_fast.hip --kernel 'jbf_pk_kernelILi11ELi2ELi16ELi16ELb0ELb1ELb0' \
             --units-per-trip 22 > profiles/k1_w11_isa_slots.txt
@@ -86,8 +88,9 @@ def main():
     print(f"# {name}")
     print(f"# {a.file}: {len(insts)} instructions; vgprs {meta.get('.vgpr_count')}, sgprs {meta.get('.sgpr_count')}, "
           f"LDS {meta.get('.group_segment_fixed_size')} B")
-    print("# slot model: 1 slot (4 cycles per SIMD) per VALU instruction, 2 per transcendental; measured costs at 4 waves/SIMD")
-    print("# (profiles/r02_valu_microbench.txt): v_pk_* / v_dot4 / v_lshl_add 3.4 cycles, v_exp_f32 6.4, v_fma_f32 / v_add_u32 2.0")
+    print("# nominal slot model of r01-r03: 1 slot (4 cycles per SIMD) per VALU instruction, 2 per transcendental.  Measured issue")
+    print("# costs (profiles/valu_costs.json, r04): v_pk_* / v_dot4 / v_lshl_add / v_cndmask / v_cmp / v_cvt 4.1-4.4 cycles, v_exp / v_rcp 8.2,")
+    print("# v_mul / v_add / v_fma_f32 / v_mov / v_and / v_add_u32 2.3-2.5 -- tools/valu_mix.py prices a kernel with their issue rates 4 / 8 / 2")
     loops = []
     for i, m, t in insts:
         if m.startswith("s_cbranch") or m == "s_branch":
