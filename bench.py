@@ -93,6 +93,10 @@ def parse():
                     help="every rank uses cuda:0 (rehearsal of the N > 1 path on a one-GPU box; needs --backend gloo)")
     ap.add_argument("--force-rccl-failure", action="store_true",
                     help="make the RCCL bring-up raise on every rank: exercises SURVEY 8(e)'s in-process fallback (gloo, [REPLICAS ONLY])")
+    ap.add_argument("--rccl-timeout", type=float, default=60.0,
+                    help="deadline in seconds of each RCCL bring-up step (the disposable probe processes, then new_group + the first "
+                         "all-reduce in the rank itself); past it the run goes on over gloo, flagged [REPLICAS ONLY]")
+    ap.add_argument("--no-rccl-probe", action="store_true", help="skip the disposable probe processes (the in-process deadline still holds)")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("KDE_BENCH_LAUNCH_TIMEOUT", "1500")),
                     help="N > 1 without a launcher: seconds after which the parent ends every rank it started (exact PIDs)")
     ap.add_argument("--first-frame", type=int, default=0, help="global index of the first frame (N = 1 runs of one shard of a larger batch)")
@@ -115,6 +119,16 @@ def launch_ranks(args):
     through HIP IPC handles -- fails in hipIpcGetMemHandle with "invalid argument".  The data path never uses IPC (frames
     are not exchanged); only RCCL's own bring-up for the parameter broadcast does."""
     import threading
+    # RCCL is tried first in N disposable probe processes (gloo rendezvous -> new_group("nccl") -> one all-reduce -> exit)
+    # under a deadline: a bring-up that hangs on one rank costs --rccl-timeout seconds and a flagged line, never the record.
+    # The verdict travels to the ranks in the environment; with a bad verdict they never touch RCCL.
+    verdict = None
+    if (args.backend == "nccl" and not args.no_rccl_probe and not args.force_rccl_failure
+            and (not args.dry_run or os.environ.get("KDE_RCCL_PROBE_TEST"))):
+        from kinectdepthmapenhancement_amd import rccl_probe
+        verdict = rccl_probe.run_probes(args.gpus, args.rccl_timeout, args.share_device)
+        print(f"bench.py: RCCL probe x{args.gpus}: {'ok' if verdict['ok'] else 'FAILED -- ' + verdict['reason']} ({verdict['seconds']} s)",
+              file=sys.stderr)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]      # released here and re-bound by rank 0's store: a stolen port fails the launch loudly (rc != 0)
@@ -122,6 +136,8 @@ def launch_ranks(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if verdict is not None:
+            env["KDE_RCCL_PROBE_VERDICT"] = json.dumps(verdict)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
     chunks = []
@@ -429,15 +445,19 @@ def main():
     local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} != --gpus {args.gpus}")
-    if 0 < args.total_frames < world:        # the same test on every rank, before any collective: all ranks leave together
-        raise SystemExit(f"--total-frames {args.total_frames} leaves some of the {world} ranks without a frame")
+    if args.total_frames > 0:                # the same test on every rank, before any collective: all ranks leave together
+        empty = [r for r, (_, c) in enumerate(sharding.partition(args.total_frames, world)) if c < 1]
+        if empty:                            # (ceil(T/N) blocks: 5 frames over 4 ranks are 2, 2, 1, 0)
+            raise SystemExit(f"--total-frames {args.total_frames} in blocks of ceil(T/N) leaves rank(s) {empty} of {world} without a frame")
     if args.share_device and args.backend == "nccl" and world > 1 and not args.force_rccl_failure:
         raise SystemExit("--share-device needs --backend gloo (RCCL wants one device per rank)")
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
     # process groups: gloo for the rendezvous, RCCL on top of it if it comes up on every rank; else the in-process
     # fallback of SURVEY 8(e) -- nothing is re-executed, the run is flagged [REPLICAS ONLY] (sharding.ShardComm)
-    comm = sharding.ShardComm(args.backend, local_rank, use_gpu=not args.dry_run, force_rccl_failure=args.force_rccl_failure)
+    verdict = json.loads(os.environ["KDE_RCCL_PROBE_VERDICT"]) if os.environ.get("KDE_RCCL_PROBE_VERDICT") else None
+    comm = sharding.ShardComm(args.backend, local_rank, use_gpu=not args.dry_run, force_rccl_failure=args.force_rccl_failure,
+                              rccl_timeout_s=args.rccl_timeout, probe=False if args.no_rccl_probe else verdict)
     barrier = comm.barrier
     use_dist = comm.active
 
@@ -460,6 +480,7 @@ def main():
     ranks_seen = int(round(comm.allreduce_sum([1.0])[0]))
     devices = comm.gather_objects(device_identity(rank, local_rank, args.dry_run))
     rccl = {"wanted": comm.rccl_wanted, "ok": comm.backend_used == "nccl", "backend_used": comm.backend_used, "error": comm.rccl_error,
+            "probe": comm.probe, "bring_up_s": comm.bringup_s, "timeout_s": args.rccl_timeout,
             "ranks_whose_block_differs_from_rank0": disagree}
 
     # ---- this rank's shard of the global batch ------------------------------------------------------

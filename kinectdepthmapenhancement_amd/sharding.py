@@ -104,25 +104,43 @@ class ShardComm:
     """The process groups of a sharded run (one process per GPU), with SURVEY 8(e)'s fallback built in.
 
     A gloo group over 127.0.0.1 is always created first: it is the rendezvous, it carries the agreement on whether RCCL is
-    usable, and it is what the run falls back to.  With backend "nccl" every rank then tries to bring up an RCCL group on
-    its own device (`new_group(backend="nccl", device_id=...)` + one all-reduce as a smoke test) INSIDE THE SAME PROCESS;
-    the ranks exchange their outcome over gloo, and RCCL is used for the parameter broadcast and the report's reductions
-    only if it came up on EVERY rank (the barriers around timed regions stay host-side, see barrier()).  Otherwise nothing is re-executed or restarted (a process that has touched
-    the GPU must not be replaced): every rank computes the parameter block itself ("replicas only"), the blocks are
-    compared over gloo, `rccl_error` holds the first exception text and the caller flags the run.
+    usable, and it is what the run falls back to.  With backend "nccl" RCCL is then brought up in two steps, neither of
+    which can outlive `rccl_timeout_s` (default 60 s, far inside the driver's 600 s limit), because a communicator that
+    cannot be built usually HANGS instead of raising:
+
+      1. probe  -- a disposable child process per rank (rccl_probe.py: gloo rendezvous -> new_group("nccl") -> one
+                   all-reduce -> exit) that is killed at the deadline.  `probe` = the verdict of the launcher's probes
+                   (bench.py's parent starts all N itself), or None: every rank starts the probe of its own rank BEFORE
+                   its first HIP call (under torch.distributed.run there is no parent of ours); False = no probe.
+                   Any probe failed or killed -> RCCL is never touched by this process.
+      2. bring-up in this process, in a helper thread (`new_group(backend="nccl", device_id=...)` + one all-reduce as a
+                   smoke test) the main thread waits for until the same deadline.  A rank that fails or gives up says so
+                   in the gloo store at once, so the healthy ranks stop waiting for it (no rank sits in an RCCL call
+                   until a c10d watchdog aborts the process: the RCCL group's own timeout is far beyond the run).
+
+    The ranks then exchange their outcome over gloo, and RCCL is used for the parameter broadcast and the report's
+    reductions only if it came up on EVERY rank (the barriers around timed regions stay host-side, see barrier()).
+    Otherwise nothing is re-executed or restarted (a process that has touched the GPU must not be replaced): every rank
+    computes the parameter block itself ("replicas only"), the blocks are compared over gloo, `rccl_error` holds the
+    first reason and the caller flags the run.  A rank whose helper thread is still inside RCCL at the end leaves
+    through os._exit in close() (a communicator that never formed cannot be destroyed).
 
     Without RANK in the environment (plain single process) every method is the identity."""
 
     def __init__(self, backend: str = "nccl", local_rank: int = 0, use_gpu: bool = True, force_rccl_failure: bool = False,
-                 timeout_s: float = 600.0):
+                 timeout_s: float = 300.0, rccl_timeout_s: float = 60.0, probe=None):
         self.active = "RANK" in os.environ
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if self.active else 1
         self.rank = int(os.environ.get("RANK", "0")) if self.active else 0
         self.local_rank = local_rank
-        self.group = None               # the group the broadcast / reductions / barriers use (None = the gloo world group)
+        self.group = None               # the group the broadcast / reductions use (None = the gloo world group)
         self.backend_used = "single process"
         self.rccl_error: Optional[str] = None
         self.rccl_wanted = backend == "nccl"
+        self.rccl_timeout_s = float(rccl_timeout_s)
+        self.probe: Optional[dict] = None       # {"ok", "reason", "seconds", "by"}
+        self.bringup_s: Optional[float] = None
+        self._stuck = False
         if not self.active:
             return
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -131,30 +149,133 @@ class ShardComm:
         self.backend_used = "gloo"
         if not self.rccl_wanted:
             return
-        if not use_gpu and not force_rccl_failure:
+        stand_in = bool(os.environ.get("KDE_RCCL_PROBE_TEST") or os.environ.get("KDE_RCCL_INPROC_TEST"))
+        if not use_gpu and not force_rccl_failure and not stand_in:
             self.backend_used = "gloo (dry run: RCCL not attempted)"
             return
-        err, g = None, None
-        try:
-            if force_rccl_failure:
-                raise RuntimeError("RCCL initialisation failure forced by --force-rccl-failure (test of the fallback)")
-            dev = torch.device("cuda", local_rank)
-            g = dist.new_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=timeout_s))
-            t = torch.ones(1, dtype=torch.float64, device=dev)
-            dist.all_reduce(t, group=g)                 # the first collective builds the communicator over xGMI
-            torch.cuda.synchronize(dev)
-            if int(t.item()) != self.world:
-                raise RuntimeError(f"RCCL all-reduce of 1 over {self.world} ranks returned {t.item()}")
-        except Exception as e:          # noqa: BLE001 -- whatever RCCL / HIP raised: the fallback takes it from here
-            err = f"{type(e).__name__}: {e}"[:400]
+        # ---- 1. the disposable probes -----------------------------------------------------------------------
+        if self.world > 1 and probe is not False and not force_rccl_failure and (use_gpu or os.environ.get("KDE_RCCL_PROBE_TEST")):
+            self.probe = dict(probe, by="launcher") if isinstance(probe, dict) else self._probe_own_rank()
+            if not self.probe["ok"]:
+                self.rccl_error = f"RCCL probe: {self.probe['reason']}"[:400]
+                self.backend_used = "gloo (RCCL unavailable)"
+                return
+        if not use_gpu and not force_rccl_failure and not os.environ.get("KDE_RCCL_INPROC_TEST"):
+            self.backend_used = "gloo (dry run: RCCL not attempted)"
+            return
+        # ---- 2. the bring-up in this process, bounded by the same deadline ----------------------------------
+        err, g = self._bring_up(use_gpu, force_rccl_failure)
         outcome = [None] * self.world
         dist.all_gather_object(outcome, err)            # over gloo: RCCL is used only if it came up on every rank
         failed = [(r, e) for r, e in enumerate(outcome) if e]
         if failed:
+            # the rank that failed by itself first, not the ones that only stopped waiting for it
+            failed.sort(key=lambda re: ("another rank" in re[1], re[0]))
             self.rccl_error = f"rank {failed[0][0]}: {failed[0][1]}" + (f" (+{len(failed) - 1} more ranks)" if len(failed) > 1 else "")
             self.backend_used = "gloo (RCCL unavailable)"
         else:
             self.group, self.backend_used = g, "nccl"
+
+    @staticmethod
+    def _store():
+        try:
+            return dist.distributed_c10d._get_default_store()
+        except Exception:               # noqa: BLE001 -- no store: the early-exit signal is lost, the deadline still holds
+            return None
+
+    def _flag(self, key: str) -> None:
+        st = self._store()
+        if st is not None:
+            try:
+                st.set(key, "1")
+            except Exception:           # noqa: BLE001
+                pass
+
+    def _flagged(self, key: str) -> bool:
+        st = self._store()
+        if st is None:
+            return False
+        try:
+            return bool(st.check([key]))
+        except Exception:               # noqa: BLE001
+            return False
+
+    def _probe_own_rank(self) -> dict:
+        """no launcher of ours: this rank starts the probe of its own rank (a fresh process; this one has not touched the GPU
+        yet), rank 0 picks the probes' port, the verdicts are gathered over gloo"""
+        from . import rccl_probe
+        port = [rccl_probe.free_port() if self.rank == 0 else None]
+        dist.broadcast_object_list(port, src=0)
+        q = rccl_probe.start_probe(self.rank, self.world, self.local_rank, port[0])
+        mine = rccl_probe.wait_probes([q], [self.rank], self.rccl_timeout_s, peer_failed=lambda: self._flagged("kde_probe_failed"))
+        if not mine["ok"]:
+            self._flag("kde_probe_failed")
+        every = [None] * self.world
+        dist.all_gather_object(every, mine)
+        bad = [v["reason"] for v in every if not v["ok"]]
+        first = [b for b in bad if "another rank" not in b] or bad
+        return {"ok": not bad, "reason": "; ".join(first[:2]) if bad else None,
+                "seconds": max(v["seconds"] for v in every), "by": "every rank, for itself"}
+
+    def _bring_up(self, use_gpu: bool, force_rccl_failure: bool):
+        """new_group("nccl") + one all-reduce in a helper thread; -> (error text | None, group | None) within the deadline"""
+        import threading
+        import time
+        box = {}
+        hang = os.environ.get("KDE_RCCL_INPROC_TEST", "")      # "hang:<rank>" / "fail:<rank>": CPU tests of the deadline
+        kind, _, who = hang.partition(":")
+        mine = kind and (who == "" or int(who) == self.rank)
+        # the RCCL group's own timeout lies far beyond the run: the c10d watchdog aborts the PROCESS when a collective
+        # exceeds it, which is exactly the empty record this class exists to prevent -- the deadline is enforced here
+        long_timeout = datetime.timedelta(seconds=max(7200.0, 10 * self.rccl_timeout_s))
+
+        def work():
+            try:
+                if force_rccl_failure:
+                    raise RuntimeError("RCCL initialisation failure forced by --force-rccl-failure (test of the fallback)")
+                if mine and kind == "hang":
+                    while True:
+                        time.sleep(1.0)
+                if mine and kind == "fail":
+                    raise RuntimeError("RCCL initialisation failure forced by KDE_RCCL_INPROC_TEST")
+                if not use_gpu:         # stand-in run on the CPU: the healthy ranks of a hang / fail test
+                    while not self._flagged("kde_rccl_failed"):
+                        time.sleep(0.05)
+                    raise RuntimeError("gave up: another rank reported a failed bring-up")
+                dev = torch.device("cuda", self.local_rank)
+                g = dist.new_group(backend="nccl", device_id=dev, timeout=long_timeout)
+                t = torch.ones(1, dtype=torch.float64, device=dev)
+                dist.all_reduce(t, group=g)             # the first collective builds the communicator over xGMI
+                torch.cuda.synchronize(dev)
+                if int(t.item()) != self.world:
+                    raise RuntimeError(f"RCCL all-reduce of 1 over {self.world} ranks returned {t.item()}")
+                box["group"] = g
+            except Exception as e:      # noqa: BLE001 -- whatever RCCL / HIP raised: the fallback takes it from here
+                box["err"] = f"{type(e).__name__}: {e}"[:400]
+
+        th = threading.Thread(target=work, name="kde-rccl-bring-up", daemon=True)
+        t0 = time.time()
+        th.start()
+        err = None
+        while th.is_alive():
+            el = time.time() - t0
+            if el >= self.rccl_timeout_s:
+                err = f"RCCL bring-up still not finished after {el:.0f} s (--rccl-timeout {self.rccl_timeout_s:g}); abandoned"
+                break
+            if self._flagged("kde_rccl_failed"):
+                th.join(2.0)            # a healthy rank's collective cannot complete any more: do not wait for the deadline
+                if th.is_alive():
+                    err = "RCCL bring-up abandoned: another rank reported a failed bring-up"
+                break
+            th.join(0.05)
+        self.bringup_s = round(time.time() - t0, 2)
+        if th.is_alive():
+            self._stuck = True
+        else:
+            err = box.get("err", err)
+        if err:
+            self._flag("kde_rccl_failed")
+        return err, box.get("group")
 
     @property
     def replicas_only(self) -> bool:
@@ -189,5 +310,11 @@ class ShardComm:
         return out
 
     def close(self) -> None:
-        if self.active and dist.is_initialized():
-            dist.destroy_process_group()
+        if not (self.active and dist.is_initialized()):
+            return
+        if self._stuck:                 # a helper thread is still inside an RCCL call that will never return: the communicator
+            import sys                  # cannot be destroyed, and interpreter shutdown would wait for it
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
+        dist.destroy_process_group()
