@@ -449,13 +449,14 @@ def main():
         empty = [r for r, (_, c) in enumerate(sharding.partition(args.total_frames, world)) if c < 1]
         if empty:                            # (ceil(T/N) blocks: 5 frames over 4 ranks are 2, 2, 1, 0)
             raise SystemExit(f"--total-frames {args.total_frames} in blocks of ceil(T/N) leaves rank(s) {empty} of {world} without a frame")
-    if args.share_device and args.backend == "nccl" and world > 1 and not args.force_rccl_failure:
-        raise SystemExit("--share-device needs --backend gloo (RCCL wants one device per rank)")
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
     # process groups: gloo for the rendezvous, RCCL on top of it if it comes up on every rank; else the in-process
     # fallback of SURVEY 8(e) -- nothing is re-executed, the run is flagged [REPLICAS ONLY] (sharding.ShardComm)
     verdict = json.loads(os.environ["KDE_RCCL_PROBE_VERDICT"]) if os.environ.get("KDE_RCCL_PROBE_VERDICT") else None
+    if args.share_device and args.backend == "nccl" and world > 1 and not args.force_rccl_failure and not (verdict and not verdict["ok"]):
+        # (with a failed probe verdict the ranks never touch RCCL: that combination is the hardware test of the probes)
+        raise SystemExit("--share-device needs --backend gloo (RCCL wants one device per rank)")
     comm = sharding.ShardComm(args.backend, local_rank, use_gpu=not args.dry_run, force_rccl_failure=args.force_rccl_failure,
                               rccl_timeout_s=args.rccl_timeout, probe=False if args.no_rccl_probe else verdict)
     barrier = comm.barrier

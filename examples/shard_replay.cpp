@@ -9,7 +9,7 @@
 // write on the same C ABI (include/kde_hip.h).
 //
 // usage: shard_replay [--frames N] [--width W] [--height H] [--window 11] [--steps K] [--warmup W] [--wakeup-ms 150]
-//                     [--devices G] [--frames-file F] [--verify] [--force-rccl-failure]
+//                     [--devices G] [--share-device G] [--frames-file F] [--verify] [--force-rccl-failure] [--rccl-timeout S]
 //   Timing follows bench.py: an untimed wake-up load (an idle MI355X sits at its lowest clock level), W warm-up steps,
 //   then K timed steps that all device threads start together; every step is K0 (kde_jbf_presmooth_batch) + K1
 //   (kde_jbf_filter_batch) -- exactly what kde_jbf_process_batch launches -- bracketed by HIP events on the device's
@@ -19,6 +19,12 @@
 //   --verify: the same N frames are also filtered on device 0 alone, as ONE block and as TWO half blocks, and the
 //             per-frame checksums of all three runs must be identical (partition independence, bit for bit).
 //   --force-rccl-failure: behave as if ncclCommInitAll had failed (test of the fallback below).
+//   --share-device G: G host threads that all use device 0, each with its own stream, kde_jbf handle and shard buffers --
+//             the code path eight GPUs take, on a one-GPU box, and the test of kde_hip.h's threading contract ("handles are
+//             independent and may be used from different threads").  RCCL wants one device per rank, so the parameter
+//             block goes the "replicas only" way.
+//   --rccl-timeout S (default 60): ncclCommInitAll runs in a helper thread; if it has not returned after S seconds the
+//             run goes on without RCCL ("replicas only", flagged) and the process leaves through _Exit at the end.
 // Fallback: if the RCCL communicators cannot be created, nothing is restarted -- every device thread forms the
 // parameter block itself ("replicas only"), compares it with rank 0's copy in host memory, and the line says so with RCCL's error.
 // prints one JSON line: per-device times and PCI addresses, aggregate Mpixels/s, checksum,
@@ -29,6 +35,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -68,8 +77,8 @@
 namespace {
 
 struct Options {
-    int frames = 64, width = 640, height = 480, window = 11, steps = 20, warmup = 5, devices = 0;
-    float spatial_sigma = 3.0f, color_sigma = 7.65f, depth_sigma = 20.0f, wakeup_ms = 150.0f;
+    int frames = 64, width = 640, height = 480, window = 11, steps = 20, warmup = 5, devices = 0, share_device = 0;
+    float spatial_sigma = 3.0f, color_sigma = 7.65f, depth_sigma = 20.0f, wakeup_ms = 150.0f, rccl_timeout_s = 60.0f;
     bool verify = false, force_rccl_failure = false;
     std::string frames_file;
 };
@@ -305,6 +314,40 @@ ShardResult run_shard(const Options& o, int device, int rank, int first, int cou
     return res;
 }
 
+// ncclCommInitAll under a deadline: a communicator that cannot be built over xGMI usually hangs instead of failing.
+// The call runs in a helper thread on state of its own; past the deadline the caller goes on without it.
+struct CommInit {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false;
+    ncclResult_t rc = ncclSystemError;
+    std::vector<ncclComm_t> comms;
+    std::vector<int> devs;
+};
+
+// -> ncclSuccess and the communicators, an RCCL error, or timed_out = true (the helper thread is then still inside RCCL)
+ncclResult_t comm_init_all(int G, float timeout_s, std::vector<ncclComm_t>& comms, bool& timed_out, bool test_hang)
+{
+    auto st = std::make_shared<CommInit>();
+    st->comms.assign(G, nullptr);
+    st->devs.resize(G);
+    for (int d = 0; d < G; d++) st->devs[d] = d;
+    std::thread([st, G, test_hang]() {
+        if (test_hang)
+            for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
+        const ncclResult_t rc = ncclCommInitAll(st->comms.data(), G, st->devs.data());
+        std::lock_guard<std::mutex> lk(st->m);
+        st->rc = rc;
+        st->done = true;
+        st->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(st->m);
+    timed_out = !st->cv.wait_for(lk, std::chrono::duration<float>(timeout_s), [&] { return st->done; });
+    if (timed_out) return ncclSystemError;
+    if (st->rc == ncclSuccess) comms = st->comms;
+    return st->rc;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -322,6 +365,8 @@ int main(int argc, char** argv)
         else if (a == "--wakeup-ms") o.wakeup_ms = (float)std::atof(next());
         else if (a == "--frames-file") o.frames_file = next();
         else if (a == "--devices") o.devices = std::atoi(next());
+        else if (a == "--share-device") o.share_device = std::atoi(next());
+        else if (a == "--rccl-timeout") o.rccl_timeout_s = (float)std::atof(next());
         else if (a == "--verify") o.verify = true;
         else if (a == "--force-rccl-failure") o.force_rccl_failure = true;
         else {
@@ -331,8 +376,9 @@ int main(int argc, char** argv)
     }
     int visible = 0;
     KDE_OK_OR_DIE(kde_device_count(&visible));
-    const int G = o.devices > 0 ? std::min(o.devices, visible) : visible;
-    if (G < 1 || o.frames < 1 || o.steps < 1) {
+    const bool shared = o.share_device > 0;
+    const int G = shared ? o.share_device : (o.devices > 0 ? std::min(o.devices, visible) : visible);
+    if (G < 1 || visible < 1 || o.frames < 1 || o.steps < 1) {
         std::fprintf(stderr, "need at least one device, frame and step\n");
         return 2;
     }
@@ -346,14 +392,19 @@ int main(int argc, char** argv)
     // one RCCL communicator per device (single process, one thread per device).  If RCCL does not come up the run goes on
     // in this process without it: every thread forms the parameter block itself and compares it with rank 0's ("replicas only")
     std::vector<ncclComm_t> comms(G, nullptr);
-    std::vector<int> devs(G);
-    for (int d = 0; d < G; d++) devs[d] = d;
     std::string broadcast_how = "rccl ncclBroadcast";
-    const ncclResult_t init_rc = o.force_rccl_failure ? ncclSystemError : ncclCommInitAll(comms.data(), G, devs.data());
+    bool rccl_stuck = false;
+    const bool test_hang = std::getenv("KDE_SHARD_REPLAY_TEST_HANG") != nullptr;      // test of the deadline
+    const ncclResult_t init_rc = (o.force_rccl_failure || shared) ? ncclSystemError
+                                                                  : comm_init_all(G, o.rccl_timeout_s, comms, rccl_stuck, test_hang);
     std::vector<float> root_block(kBlockLen, 0.0f);
     if (init_rc != ncclSuccess) {
         std::fill(comms.begin(), comms.end(), nullptr);
-        broadcast_how = std::string("replicas only (ncclCommInitAll: ") + (o.force_rccl_failure ? "failure forced by --force-rccl-failure" : ncclGetErrorString(init_rc)) + ")";
+        char why[160];
+        std::snprintf(why, sizeof(why), "not finished after %g s, abandoned", o.rccl_timeout_s);
+        broadcast_how = shared ? std::string("replicas only (--share-device: ") + std::to_string(G) + " host threads on device 0, RCCL wants one device per rank)"
+                               : std::string("replicas only (ncclCommInitAll: ") +
+                                     (o.force_rccl_failure ? "failure forced by --force-rccl-failure" : rccl_stuck ? why : ncclGetErrorString(init_rc)) + ")";
         std::fprintf(stderr, "shard_replay: RCCL unavailable, %s\n", broadcast_how.c_str());
         KDE_OK_OR_DIE(kde_set_device(0));
         kde_jbf* probe = nullptr;
@@ -374,7 +425,7 @@ int main(int argc, char** argv)
     for (int d = 0; d < G; d++)
         threads.emplace_back([&, d]() {
             const int first = std::min(d * per, o.frames), count = std::min(per, o.frames - first);
-            results[d] = run_shard(o, d, d, first, count, comms[d], p, &barrier, &root_block);
+            results[d] = run_shard(o, shared ? 0 : d, d, first, count, comms[d], p, &barrier, &root_block);
         });
     for (auto& t : threads) t.join();
     const double wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -410,13 +461,19 @@ int main(int argc, char** argv)
         verified = one.frame_hash == hashes && two == hashes;
     }
     const double mpix = (double)o.frames * o.width * o.height / (slowest * 1e-3) / 1e6;
-    std::printf("{\"devices\": %d, \"frames\": %d, \"frames_per_device\": %d, \"width\": %d, \"height\": %d, \"window\": %d, "
+    std::printf("{\"devices\": %d, \"host_threads\": %d, \"frames\": %d, \"frames_per_device\": %d, \"width\": %d, \"height\": %d, \"window\": %d, "
                 "\"steps\": %d, \"warmup\": %d, \"wakeup_steps_before_warmup\": %d, \"input\": \"%s\", "
                 "\"ms_per_step_slowest_device\": %.4f, \"mpixels_per_s\": %.1f, \"per_device\": %s, \"params_broadcast\": \"%s\", "
                 "\"tables_match_rank0\": %s, \"checksum\": \"%016llx\", \"verified\": %s, \"wall_s\": %.2f}\n",
-                G, o.frames, per, o.width, o.height, o.window, o.steps, o.warmup, results[0].wakeup_steps,
+                shared ? 1 : G, G, o.frames, per, o.width, o.height, o.window, o.steps, o.warmup, results[0].wakeup_steps,
                 o.frames_file.empty() ? "built-in generator" : "frames file (bench.py --dump-frames)", slowest, mpix, per_dev.c_str(),
                 broadcast_how.c_str(), tables_ok ? "true" : "false",
                 (unsigned long long)all, o.verify ? (verified ? "true" : "false") : "null", wall_s);
-    return (tables_ok && verified) ? 0 : 1;
+    const int rc = (tables_ok && verified) ? 0 : 1;
+    if (rccl_stuck) {           // the helper thread is still inside ncclCommInitAll: no static destructor may wait for it
+        std::fflush(stdout);
+        std::fflush(stderr);
+        std::_Exit(rc);
+    }
+    return rc;
 }

@@ -7,6 +7,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -134,6 +135,51 @@ def test_one_rank_under_a_launcher_brings_rccl_up(torch_cuda):
                         "--no-extra", "--no-verify", "--wakeup-ms", "0"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert j["rccl"] == {"wanted": True, "ok": True, "backend_used": "nccl", "error": None, "ranks_whose_block_differs_from_rank0": 0}
+    rc = j["rccl"]
+    assert (rc["wanted"], rc["ok"], rc["backend_used"], rc["error"], rc["ranks_whose_block_differs_from_rank0"]) == (True, True, "nccl", None, 0)
+    assert rc["probe"] is None and 0 <= rc["bring_up_s"] < rc["timeout_s"] == 60.0      # one rank: no probe; the bounded bring-up ran
     assert j["ranks_seen"] == 1 and j["devices"][0]["arch"].startswith("gfx950") and len(j["devices"][0]["pci_bus_id"]) >= 7
     assert j["replicas_only"] is False and "(nccl)" in j["config"]["sharding"]
+
+
+def test_a_real_rccl_failure_is_caught_by_the_probes(torch_cuda):
+    """the closest a one-GPU box gets to a broken node: two ranks asked to build an RCCL communicator on the SAME device, which
+    RCCL refuses (or never completes).  The launcher's disposable probes -- real processes, real new_group("nccl") on the GPU --
+    fail or are killed at the deadline; the two ranks then never touch RCCL, filter their shards over gloo, and the line is
+    complete, flagged, and its checksum equals the healthy gloo run's"""
+    common = ["--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-extra", "--no-verify", "--wakeup-ms", "0", "--frames-per-gpu", "8"]
+    t0 = time.time()
+    bad = _bench(["--gpus", "2", "--share-device", "--backend", "nccl", "--rccl-timeout", "45"] + common)
+    assert time.time() - t0 < 240
+    good = _bench(["--gpus", "2", "--share-device", "--backend", "gloo"] + common)
+    assert bad["rccl"]["probe"]["ok"] is False and bad["rccl"]["probe"]["by"] == "launcher" and bad["rccl"]["bring_up_s"] is None
+    assert bad["replicas_only"] is True and "[REPLICAS ONLY]" in bad["config"]["sharding"] and "RCCL probe" in bad["rccl"]["error"]
+    assert bad["checksum"] == good["checksum"] and bad["value"] > 0 and bad["ranks_seen"] == 2
+
+
+@pytest.mark.parametrize("threads", [2, 8])
+def test_cpp_host_threads_share_one_device(torch_cuda, threads):
+    """kde_hip.h's threading contract, exercised: G host threads on device 0, each with its own stream, kde_jbf handle and shard
+    buffers, all starting their timed steps together (the code path eight GPUs take).  The per-frame hashes must equal the
+    one-thread runs of the same frames (one block, two half blocks): bit for bit, whatever the interleaving of the launches"""
+    exe = os.path.join(ROOT, "examples", "shard_replay")
+    r = subprocess.run([exe, "--share-device", str(threads), "--frames", "40", "--width", "320", "--height", "240", "--steps", "6", "--warmup", "2",
+                        "--wakeup-ms", "20", "--verify"], capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["host_threads"] == threads and line["devices"] == 1 and len(line["per_device"]) == threads
+    assert len({d["pci_bus_id"] for d in line["per_device"]}) == 1
+    assert line["verified"] is True and line["tables_match_rank0"] is True and line["mpixels_per_s"] > 0
+    assert line["params_broadcast"].startswith("replicas only (--share-device")
+
+
+def test_cpp_host_bounds_ncclCommInitAll(torch_cuda):
+    """a communicator bring-up that never returns (stand-in: the helper thread sleeps) costs --rccl-timeout seconds, not the run"""
+    exe = os.path.join(ROOT, "examples", "shard_replay")
+    t0 = time.time()
+    r = subprocess.run([exe, "--frames", "6", "--width", "160", "--height", "120", "--steps", "2", "--verify", "--rccl-timeout", "3"],
+                       capture_output=True, text=True, timeout=240, env=dict(os.environ, KDE_SHARD_REPLAY_TEST_HANG="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "not finished after 3 s, abandoned" in line["params_broadcast"] and line["verified"] is True
+    assert time.time() - t0 < 120
