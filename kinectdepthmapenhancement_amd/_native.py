@@ -132,6 +132,15 @@ SIGNATURES = {
 }
 
 
+def use_library(path: str) -> None:
+    """Bind to another build of the same sources instead of libkde_hip.so -- the measurement builds under tools/hooks/
+    (libkde_hip_ab.so: A/B switches).  Must be called before the first lib(); the product never calls it."""
+    global LIB_PATH
+    if _lib is not None and os.path.abspath(path) != os.path.abspath(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is already loaded")
+    LIB_PATH = os.path.abspath(path)
+
+
 def lib() -> C.CDLL:
     """Load libkde_hip.so; raises if it is not built (no fallback)."""
     global _lib

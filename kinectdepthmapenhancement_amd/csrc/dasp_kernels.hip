@@ -660,7 +660,7 @@ int launch_dasp_calc_ld_dual(const DaspGeom& g, int n, const uint8_t* bgr, const
 
 static int analyze_band_walk()
 {
-    static const int v = getenv("KDE_K8_NO_BAND_WALK") == nullptr ? 1 : 0;
+    static const int v = KDE_AB_ENV("KDE_K8_NO_BAND_WALK") == nullptr ? 1 : 0;      // (measurement build only)
     return v;
 }
 

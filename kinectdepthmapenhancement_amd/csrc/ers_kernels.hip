@@ -1226,10 +1226,13 @@ static int launch_ers_enhance_one(int width, int height, int n, const float* rd,
         for (int k = 49; k >= 1 && d.tthr[k] >= -1.0f; k--) d.kfree = k;
         KDE_STAGE(d.stage_avg = g_stage.ers_avg; d.stage_dev = g_stage.ers_dev; d.stage_counters = g_stage.counters;
                   d.stage_force = g_stage.force_full_rules;)
-        static const bool mask_product = getenv("KDE_K10_MASK_PRODUCT") != nullptr;      // A/B switch (r03's pass-1 label test)
         const dim3 grid((unsigned)(ceil_div(width, kE7BX * 2) * ceil_div(height, kE7BY) * n));
+#ifdef KDE_AB_SWITCHES
+        static const bool mask_product = KDE_AB_ENV("KDE_K10_MASK_PRODUCT") != nullptr;  // r03's pass-1 label test (tools/ab_k10.py)
         if (mask_product) hipLaunchKernelGGL(enhance7_pk_kernel<false>, grid, dim3(kE7BX * kE7BY), 0, s, d);
-        else hipLaunchKernelGGL(enhance7_pk_kernel<true>, grid, dim3(kE7BX * kE7BY), 0, s, d);
+        else
+#endif
+            hipLaunchKernelGGL(enhance7_pk_kernel<true>, grid, dim3(kE7BX * kE7BY), 0, s, d);
         KDE_HIP_TRY(hipGetLastError());
         return KDE_OK;
     }

@@ -386,6 +386,7 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
     }
 }
 
+#ifdef KDE_AB_SWITCHES      // measured slower than the row-pair kernel: compiled for tools/bench_k0.py only (tools/hooks/libkde_hip_ab.so)
 // --------------------------------------------------------------------------------------------
 // K0, 2 x 2 pixels per thread (r03; opt-in, KDE_K0_2X2=1: measured slower than the row-pair kernel above).  The kernel above is bound by the VALU instructions
 // it issues (184 per pixel at radius 2: 45 byte -> float conversions, 65 for the 13 taps, ~50 for the quotient /
@@ -568,6 +569,7 @@ __global__ __launch_bounds__(kPreBX* kPreBY, WAVES) void presmooth22_kernel(PreD
         }
     }
 }
+#endif  // KDE_AB_SWITCHES
 
 // K0 for any radius (OpenCV accepts any kernel size; the reference's call site uses 5): one thread per pixel, taps
 // read through the caches with reflect-101 addressing, weights from the same host-computed table (in global memory:
@@ -723,13 +725,15 @@ int launch_jbf(const JbfLaunch& a, hipStream_t s)
 #endif
 constexpr int kPrePxPerThread = KDE_K0_PX;                  // pixels per thread (A/B: -DKDE_K0_PX=4, tools/ab_k0_build.sh)
 
-// A/B switch (tools/bench_k0.py): KDE_K0_2X2=1 selects the 2 x 2-pixels-per-thread form for radii 1 and 2.  It issues 25 %
+// A/B switch of the measurement build (tools/bench_k0.py): KDE_K0_2X2=1 selects the 2 x 2-pixels-per-thread form for radii 1 and 2.  It issues 25 %
 // fewer instructions but needs 146 VGPRs (3 waves per SIMD instead of 6) and measured 0.146 vs 0.115 ms on 64 x VGA.
+#ifdef KDE_AB_SWITCHES
 static bool k0_use_2x2()
 {
-    static const bool v = getenv("KDE_K0_2X2") != nullptr;
+    static const bool v = KDE_AB_ENV("KDE_K0_2X2") != nullptr;
     return v;
 }
+#endif
 
 long long presmooth_resident_blocks(int radius)
 {
@@ -744,9 +748,11 @@ long long presmooth_resident_blocks(int radius)
         }
         return (long long)cus * per_cu;
     };
+    KDE_AB(if (k0_use_2x2() && radius == 1) return resident(presmooth22_kernel<1, kPre22Waves>);
+           if (k0_use_2x2() && radius == 2) return resident(presmooth22_kernel<2, kPre22Waves>);)
     switch (radius) {
-        case 1: return k0_use_2x2() ? resident(presmooth22_kernel<1, kPre22Waves>) : resident(presmooth_kernel<1, kPrePxPerThread>);
-        case 2: return k0_use_2x2() ? resident(presmooth22_kernel<2, kPre22Waves>) : resident(presmooth_kernel<2, kPrePxPerThread>);
+        case 1: return resident(presmooth_kernel<1, kPrePxPerThread>);
+        case 2: return resident(presmooth_kernel<2, kPrePxPerThread>);
         case 3: return resident(presmooth_kernel<3, kPrePxPerThread>);     // radii 3, 4: the 2 x 2 form needs > 300 VGPRs
         case 4: return resident(presmooth_kernel<4, kPrePxPerThread>);
         default: return 0;                                  // generic kernel: a plain grid
@@ -774,12 +780,20 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
     d.height = a.height;
     d.n = a.n;
     constexpr int kPX = kPrePxPerThread;
-    const bool old_form = a.radius > 2 || !k0_use_2x2();
-    // KDE_K0_BAND_WALK=0/1 forces the walk (A/B: tools/ab_k0_band.sh, tools/bench_k0.py); default: see k0_band_walk()
-    static const int force = [] { const char* e = getenv("KDE_K0_BAND_WALK"); return e ? (e[0] != '0' ? 1 : 0) : -1; }();
-    d.band_walk = force >= 0 ? force : k0_band_walk(a.width, a.height, a.n);
-    d.tiles_x = ceil_div(a.width, old_form ? kPreBX * kPX : kPre22TW);
-    d.tiles_y = ceil_div(a.height, old_form ? kPreTH : kPre22TH);
+    bool old_form = true;
+    d.band_walk = k0_band_walk(a.width, a.height, a.n);
+    d.tiles_x = ceil_div(a.width, kPreBX * kPX);
+    d.tiles_y = ceil_div(a.height, kPreTH);
+#ifdef KDE_AB_SWITCHES
+    // measurement build only: KDE_K0_2X2 selects the 2 x 2 form, KDE_K0_BAND_WALK=0/1 forces the walk (tools/ab_k0_band.sh, tools/bench_k0.py)
+    old_form = a.radius > 2 || !k0_use_2x2();
+    static const int force = [] { const char* e = KDE_AB_ENV("KDE_K0_BAND_WALK"); return e ? (e[0] != '0' ? 1 : 0) : -1; }();
+    if (force >= 0) d.band_walk = force;
+    if (!old_form) {
+        d.tiles_x = ceil_div(a.width, kPre22TW);
+        d.tiles_y = ceil_div(a.height, kPre22TH);
+    }
+#endif
     if (a.radius < 1) return fail(KDE_ERR_INVALID, "presmooth: radius %d", a.radius);
     if (a.radius > 4) {
         if (a.n > 65535) return fail(KDE_ERR_INVALID, "presmooth: batch too large for one launch");
@@ -801,10 +815,13 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
             case 3: hipLaunchKernelGGL((presmooth_kernel<3, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
             default: hipLaunchKernelGGL((presmooth_kernel<4, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;
         }
-    } else {
+    }
+#ifdef KDE_AB_SWITCHES
+    else {
         if (a.radius == 1) hipLaunchKernelGGL((presmooth22_kernel<1, kPre22Waves>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d);
         else hipLaunchKernelGGL((presmooth22_kernel<2, kPre22Waves>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d);
     }
+#endif
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }

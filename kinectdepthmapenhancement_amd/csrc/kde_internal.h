@@ -33,6 +33,18 @@ int fail(int code, const char* fmt, ...);   // records the message for kde_last_
         if (rc_ != KDE_OK) return rc_; \
     } while (0)
 
+// A/B switches (environment variables that select a rejected or alternative kernel) exist only in the measurement build
+// tools/hooks/libkde_hip_ab.so (-DKDE_AB_SWITCHES): the product library reads no environment variable and carries none of
+// the kernels that were measured slower and dropped.  KDE_AB_ENV(name) is getenv there and a constant nullptr here.
+#ifdef KDE_AB_SWITCHES
+#include <cstdlib>
+#define KDE_AB_ENV(name) (::getenv(name))
+#define KDE_AB(...) __VA_ARGS__
+#else
+#define KDE_AB_ENV(name) (static_cast<const char*>(nullptr))
+#define KDE_AB(...)
+#endif
+
 #define KDE_REQUIRE(cond, ...)                                   \
     do {                                                         \
         if (!(cond)) return ::kde::fail(KDE_ERR_INVALID, __VA_ARGS__); \

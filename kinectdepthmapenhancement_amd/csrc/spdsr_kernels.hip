@@ -325,6 +325,7 @@ __global__ __launch_bounds__(kSwBX* kSwBY) void mrf_sweep_kernel(int width, int 
     if (has1) zout[p + 1] = rw1 ? -oz.y : oz.y;
 }
 
+#ifdef KDE_AB_SWITCHES      // measured slower: compiled for tools/bench_spdsr.py and the bit-identity test only
 // Two sweeps per launch (temporal blocking) -- MEASURED AND NOT USED BY DEFAULT (KDE_SPDSR_TWO_SWEEPS=1 selects it).
 // A single sweep moves 12 B per pixel and is half latency (VALU busy 0.43 at 1080p, 20 launches of 16 us each); here a
 // workgroup that owns a 64 x 32 tile stages the z plane with a halo of 4, evaluates sweep k on the tile + a halo of 2
@@ -445,6 +446,7 @@ __global__ __launch_bounds__(256) void mrf_sweep2_kernel(int width, int height, 
         if (x + 1 < width) zout[p + 1] = r.y;
     }
 }
+#endif  // KDE_AB_SWITCHES
 
 __global__ __launch_bounds__(kThreads) void mrf_expand_kernel(int npix, const float* __restrict__ zfinal,
                                                              const kde_float3* __restrict__ pts,
@@ -522,18 +524,20 @@ int launch_spdsr_plane_projection(int width, int height, int n, int nclusters, c
                        zping, pfz);
     float *in = zping, *out = zpong;
     dim3 grid((unsigned)(ceil_div(width, kSwBX * 2) * ceil_div(height, kSwBY) * n));
-    static const int band = getenv("KDE_SWEEP_NO_BAND_WALK") == nullptr ? 1 : 0;      // A/B switch for tools/bench_spdsr.py
+    static const int band = KDE_AB_ENV("KDE_SWEEP_NO_BAND_WALK") == nullptr ? 1 : 0;      // (measurement build only)
+    int i = 0;
+#ifdef KDE_AB_SWITCHES
     // A/B switch for tools/bench_spdsr.py.  Measured on MI355X (r03): two sweeps per launch are bit-identical and SLOWER --
     // 0.978 vs 0.946 ms per 1080p frame, 0.383 vs 0.333 at 640x480 (150 workgroups there) -- so one sweep per launch stays.
-    static const bool two_sweeps = getenv("KDE_SPDSR_TWO_SWEEPS") != nullptr;
+    static const bool two_sweeps = KDE_AB_ENV("KDE_SPDSR_TWO_SWEEPS") != nullptr;
     dim3 grid2(ceil_div(width, kSw2TW), ceil_div(height, kSw2TH), n);
-    int i = 0;
     for (; two_sweeps && i + 1 < sweeps; i += 2) {      // two sweeps per launch (mrf_sweep2_kernel)
         hipLaunchKernelGGL(mrf_sweep2_kernel, grid2, dim3(256), 0, s, width, height, in, pfz, out);
         float* t = in;
         in = out;
         out = t;
     }
+#endif
     for (; i < sweeps; i++) {
         hipLaunchKernelGGL(mrf_sweep_kernel, grid, dim3(kSwBX * kSwBY), 0, s, width, height, in, pfz, out, band);
         float* t = in;

@@ -102,6 +102,25 @@ def test_product_does_not_reference_the_oracle():
     assert "oracle" not in out
 
 
+def test_product_library_reads_no_environment_variable():
+    """the A/B switches (and the kernels that were measured slower and dropped) live in the measurement
+    build tools/hooks/libkde_hip_ab.so (-DKDE_AB_SWITCHES) only -- the product library does not even import getenv, and
+    carries none of the rejected kernels"""
+    from kinectdepthmapenhancement_amd import _native
+    syms = subprocess.run(["nm", "-D", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
+    blob = open(_native.LIB_PATH, "rb").read()
+    for name in (b"presmooth22_kernel", b"mrf_sweep2_kernel", b"KDE_K0_2X2", b"KDE_K0_BAND_WALK", b"KDE_K10_MASK_PRODUCT",
+                 b"KDE_K8_NO_BAND_WALK", b"KDE_SWEEP_NO_BAND_WALK", b"KDE_SPDSR_TWO_SWEEPS"):
+        assert name not in blob, name
+    for f in ("jbf_kernels.hip", "jbf_fast.hip", "ers_kernels.hip", "dasp_kernels.hip", "spdsr_kernels.hip", "stream_kernels.hip", "kde_api.cpp"):
+        txt = open(os.path.join(_native.CSRC, f)).read()
+        assert "getenv(" not in txt.replace("::getenv(name)", ""), f       # only through KDE_AB_ENV (kde_internal.h)
+    ab = os.path.join(ROOT, "tools", "hooks", "libkde_hip_ab.so")
+    if os.path.exists(ab):
+        assert "getenv" in subprocess.run(["nm", "-D", ab], capture_output=True, text=True, check=True).stdout
+
+
 def test_every_entry_point_rejects_null_arguments_without_a_gpu():
     """Every int-returning entry point that takes a handle or an out-pointer first is called with all-zero arguments in a
     child process: the answer must be KDE_ERR_INVALID (validation precedes any HIP call) — `*_destroy(NULL)` is a no-op like

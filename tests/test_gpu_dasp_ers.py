@@ -636,14 +636,17 @@ def test_spdsr_object_reuse_starts_from_clean_moment_tables(torch_cuda, F, oracl
 
 def test_spdsr_two_sweeps_per_launch_equal_single_sweeps_bitwise(torch_cuda, tmp_path):
     """The measured-and-rejected two-sweeps-per-launch form of Projection_GPU's 20 mrf_optimization sweeps
-    (mrf_sweep2_kernel, KDE_SPDSR_TWO_SWEEPS=1, read once per process): per pixel the arithmetic is the single-sweep
-    kernel's, so the optimised cloud must not change by a bit.  Ragged size: partial tiles and an odd width."""
+    (mrf_sweep2_kernel; only in the measurement build tools/hooks/libkde_hip_ab.so, selected there by KDE_SPDSR_TWO_SWEEPS=1,
+    read once per process): per pixel the arithmetic is the single-sweep kernel's, so the optimised cloud must not change by
+    a bit against the PRODUCT library's.  Ragged size: partial tiles and an odd width."""
     import os
     import subprocess
     import sys
     from conftest import ROOT
     code = (
-        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "import os, sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "if os.environ.get('KDE_SPDSR_TWO_SWEEPS'):\n"
+        "    sys.path.insert(0, os.path.join(sys.path[0], 'tools', 'hooks')); import ab; ab.use_ab_library()\n"
         "from kinectdepthmapenhancement_amd import filters as F, synth\n"
         "from oracle import oracle as O\n"
         "outs = []\n"

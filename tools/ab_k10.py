@@ -15,6 +15,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools", "hooks"))
+import ab as _ab                                    # noqa: E402
+_ab.use_ab_library()                                # both legs on tools/hooks/libkde_hip_ab.so: only that build has the switch
 
 
 def child():

@@ -11,6 +11,9 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hooks"))
+import ab as _ab                                    # noqa: E402
+_ab.use_ab_library_if_switched()                    # a KDE_* A/B switch in the environment -> tools/hooks/libkde_hip_ab.so
 
 
 def timed(torch, fn, iters):
