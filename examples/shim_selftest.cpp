@@ -112,6 +112,68 @@ int main()
     HIP_OK(hipMemcpy(dev_copy.data(), mrf.getFiltered_Device(), px * 4, hipMemcpyDeviceToHost));
     expect(std::memcmp(host, dev_copy.data(), px * 4) == 0, "MRF getFiltered_Host mirrors Filtered_Device");
 
+    // ---- viewer members (host side; the reference's windows are out of scope, the pictures are not) ----
+    {
+        uint8_t c[3];
+        struct { float r; int b, g, rr; } known[] = {{0.165f, 127, 0, 0}, {0.5f, 123, 131, 0}, {0.8f, 0, 146, 108}, {2.0f, 0, 0, 254},
+                                                     {0.0f, 0, 0, 0}, {0.33f, 255, 0, 0}, {0.66f, 0, 254, 0}};
+        bool ramp_ok = true;
+        for (auto& k : known) {
+            kde::viewers::depth_ramp(k.r, c);
+            ramp_ok = ramp_ok && c[0] == k.b && c[1] == k.g && c[2] == k.rr;
+        }
+        expect(ramp_ok, "depth ramp reproduces the reference's getRGB at known ratios");
+        std::vector<float> in(px);
+        HIP_OK(hipMemcpy(in.data(), d_depth, px * 4, hipMemcpyDeviceToHost));
+        mrf.visualize(in.data());
+        jbf.Process(d_depth, good);
+        jbf.visualize(in.data());                    // refreshes Filtered_Host, renders both pictures
+        std::vector<float> filt(px);
+        HIP_OK(hipMemcpy(filt.data(), jbf.getFiltered_Device(), px * 4, hipMemcpyDeviceToHost));
+        bool pic_ok = jbf.getOutputDepthImage().rows == H && jbf.getInputDepthImage().cols == W;
+        for (size_t q = 0; q < px && pic_ok; q++) {
+            uint8_t e[3] = {0, 0, 0};
+            if (filt[q] > 50.0f) kde::viewers::depth_ramp(filt[q] / 5000.0f, e);
+            const uint8_t* got = jbf.getOutputDepthImage().data() + q * 3;
+            pic_ok = got[0] == e[0] && got[1] == e[1] && got[2] == e[2];
+            const uint8_t* gin = jbf.getInputDepthImage().data() + q * 3;
+            if (!(in[q] > 50.0f)) pic_ok = pic_ok && gin[0] == 0 && gin[1] == 0 && gin[2] == 0;
+        }
+        expect(pic_ok, "JointBilateralFilter::visualize renders input and filtered depth (invalid pixels black)");
+        // EdgeRefinedSuperpixel viewers on a real refinement
+        ers.EdgeRefining(dasp.getLabelDevice(), dasp.getLabelDevice(), d_depth, good);
+        const int* lab = ers.getRefinedLabels_Host();
+        const float* rd = ers.getRefinedDepth_Host();
+        kde::HostImage8UC3& seg = ers.getSegmentedImage(3000);
+        std::vector<uint8_t> host_bgr(px * 3);
+        HIP_OK(hipMemcpy(host_bgr.data(), d_bgr, px * 3, hipMemcpyDeviceToHost));
+        struct HostMat { uint8_t* data; int rows, cols; size_t step; } hm{host_bgr.data(), H, W, (size_t)W * 3};
+        kde::HostImage8UC3& lines = ers.getSegmentedImage(hm);
+        kde::HostImage8UC3& rnd = ers.getRandomColorImage();
+        bool seg_ok = true, border_seen = false;
+        for (int y = 0; y + 1 < H && seg_ok; y++)
+            for (int x = 0; x + 1 < W && seg_ok; x++) {
+                const size_t q = (size_t)y * W + x;
+                const bool border = lab[q] != lab[q + W] || lab[q] != lab[q + 1];
+                border_seen = border_seen || border;
+                const uint8_t* a = seg.at(y, x);
+                const uint8_t* b = lines.at(y, x);
+                if (border) seg_ok = a[0] == 255 && a[1] == 255 && a[2] == 255 && b[0] == 255 && b[1] == 255 && b[2] == 255;
+                else {
+                    seg_ok = std::memcmp(b, host_bgr.data() + q * 3, 3) == 0;
+                    if (rd[q] == 0.0f && lab[q] != -100) seg_ok = seg_ok && a[0] == 0 && a[1] == 0 && a[2] == 0;
+                }
+                // one colour per label
+                if (lab[q] == lab[q + 1]) seg_ok = seg_ok && std::memcmp(rnd.at(y, x), rnd.at(y, x + 1), 3) == 0;
+            }
+        expect(seg_ok && border_seen, "EdgeRefinedSuperpixel viewers: borders white, holes black, one colour per label");
+        kde::HostImage8UC3& avg = dasp.getSegmentedImage(hm, DepthAdaptiveSuperpixel::Average);
+        kde::HostImage8UC3& dl = dasp.getSegmentedImage(hm, DepthAdaptiveSuperpixel::Line);
+        dasp.getRandomColorImage();
+        dasp.releaseVideo();
+        expect(avg.rows == H && dl.cols == W, "DepthAdaptiveSuperpixel viewers render");
+    }
+
     // ---- ProcessBatch == per-frame Process, to the bit ----
     RegionGrowingBilateralFilter rgb(W, H, N);
     rgb.SetParametor(6, 8, K);

@@ -20,6 +20,8 @@
 //     CUDA return code); nothing aborts;
 //   * every object owns one stream-ordered context; an optional stream (void* = hipStream_t) can be set
 //     with setStream(), default is the null stream like the reference;
+//   * the viewer members (visualize, getSegmentedImage, getRandomColorImage) render into object-owned host images
+//     (kde::HostImage8UC3, viewers.hpp) instead of cv::Mat_ / cv::imshow windows; releaseVideo() is a no-op;
 //   * classes live in the global namespace like the reference's unless KDE_NO_GLOBAL_NAMES is defined
 //     (then they are only reachable as kde::ref::Name).
 #ifndef KDE_KDE_HPP
@@ -31,6 +33,7 @@
 #include <string>
 
 #include "../kde_hip.h"
+#include "viewers.hpp"   // host-side renderers behind visualize() / getSegmentedImage() / getRandomColorImage()
 
 #if defined(__has_include)
 #if __has_include(<hip/hip_vector_types.h>)
@@ -141,10 +144,22 @@ public:
         check(kde_jbf_smooth_device(h_, &p));
         return GpuImage8UC3{p, Height, Width, static_cast<size_t>(Width) * 3};
     }
+    // void visualize(float* depth_host) (JointBilateralFilter.h:18, .cpp:50-79): refreshes Filtered_Host (in the reference this
+    // member is the ONLY thing that does) and renders the caller's input depth and the filtered depth with the reference's
+    // ramp over 5000 mm, pixels <= 50 mm black.  The reference then shows both with cv::imshow + cv::waitKey(1); windows are
+    // outside the scope, the pictures are kept in the object instead (getInputDepthImage / getOutputDepthImage).
+    void visualize(float* depth_host)
+    {
+        if (InputDepth.rows != Height) InputDepth = HostImage8UC3(Height, Width), OutputDepth = HostImage8UC3(Height, Width);
+        viewers::render_depth(depth_host, 5000.0f, true, 50.0f, InputDepth);
+        viewers::render_depth(getFiltered_Host(), 5000.0f, true, 50.0f, OutputDepth);
+    }
+    HostImage8UC3& getInputDepthImage() { return InputDepth; }       // extension: what "depth_input" would have shown
+    HostImage8UC3& getOutputDepthImage() { return OutputDepth; }     // extension: what "depth_filtered" would have shown
     void setStream(void* hip_stream) { stream_ = hip_stream; }
     kde_jbf* handle() const { return h_; }
     // extension: the name of the kernel this object's parameters select ("generic-32x8-1px" when no tuned one applies:
-    // windows 1 and 23-31, a zero sigma); kde_jbf_active_variant
+    // window 1, a zero sigma, or a colour sigma outside the tuned range); kde_jbf_active_variant
     const char* activeKernel() const
     {
         int v = 0;
@@ -156,6 +171,7 @@ private:
     int Width, Height;
     kde_jbf* h_ = nullptr;
     void* stream_ = nullptr;
+    HostImage8UC3 InputDepth, OutputDepth;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -187,12 +203,25 @@ public:
         check(kde_mrf_filtered_host(h_, stream_, &p));
         return const_cast<float*>(p);
     }
+    // cv::gpu::GpuMat getSmoothImage_Device() (MarkovRandomField.h:17): the reference allocates smooth_Device and never
+    // writes it (MarkovRandomField.cpp:13, no kernel takes it) -- there is nothing to return but an empty image
+    GpuImage8UC3 getSmoothImage_Device() { return GpuImage8UC3{nullptr, 0, 0, 0}; }
+    // void visualize(float* depth_host) (MarkovRandomField.h:18, .cpp:50-79): as JointBilateralFilter::visualize
+    void visualize(float* depth_host)
+    {
+        if (InputDepth.rows != Height) InputDepth = HostImage8UC3(Height, Width), OutputDepth = HostImage8UC3(Height, Width);
+        viewers::render_depth(depth_host, 5000.0f, true, 50.0f, InputDepth);
+        viewers::render_depth(getFiltered_Host(), 5000.0f, true, 50.0f, OutputDepth);
+    }
+    HostImage8UC3& getInputDepthImage() { return InputDepth; }
+    HostImage8UC3& getOutputDepthImage() { return OutputDepth; }
     void setStream(void* hip_stream) { stream_ = hip_stream; }
 
 private:
     int Width, Height;
     kde_mrf* h_ = nullptr;
     void* stream_ = nullptr;
+    HostImage8UC3 InputDepth, OutputDepth;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -312,12 +341,48 @@ public:
         check(kde_dasp_mean_device(h_, &p));
         return p;
     }
+    // ---- viewer members of the base class (SuperpixelSegmentation.h:36-41, .cpp:50-200); host side, no window, no video ----
+    static const int Line = 0, Average = 1;
+    // options == Line: the input with segment borders in white; otherwise every pixel in its cluster's mean colour
+    // (.r,.g,.b into channels 0,1,2 as the reference writes them), label -1 black
+    template <class ImageLike>
+    HostImage8UC3& getSegmentedImage(const ImageLike& input_host, int options)
+    {
+        const int32_t* labels = nullptr;
+        check(kde_dasp_labels_host(h_, stream_, &labels));
+        if (SegmentedColor.rows != Height) SegmentedColor = HostImage8UC3(Height, Width);
+        if (options == Line) {
+            viewers::copy_from(input_host, SegmentedColor);
+            viewers::mark_label_borders(labels, SegmentedColor);
+        } else {
+            const superpixel* mean = nullptr;
+            int count = 0;
+            check(kde_dasp_mean_host(h_, stream_, &mean, &count));
+            for (int y = 0; y < Height; y++)
+                for (int x = 0; x < Width; x++) {
+                    const int32_t id = labels[static_cast<size_t>(y) * Width + x];
+                    if (id >= 0 && id < count) SegmentedColor.set(y, x, mean[id].r, mean[id].g, mean[id].b);
+                    else SegmentedColor.set(y, x, 0, 0, 0);
+                }
+        }
+        return SegmentedColor;
+    }
+    HostImage8UC3& getRandomColorImage()
+    {
+        const int32_t* labels = nullptr;
+        check(kde_dasp_labels_host(h_, stream_, &labels));
+        if (SegmentedRandomColor.rows != Height) SegmentedRandomColor = HostImage8UC3(Height, Width);
+        viewers::render_random_colours(labels, SegmentedRandomColor);
+        return SegmentedRandomColor;
+    }
+    void releaseVideo() {}      // the reference's constructor opens an .avi writer (SuperpixelSegmentation.cpp:9); this one does not
     void setStream(void* hip_stream) { stream_ = hip_stream; }
 
 private:
     int Width, Height;
     kde_dasp* h_ = nullptr;
     void* stream_ = nullptr;
+    HostImage8UC3 SegmentedColor, SegmentedRandomColor;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -358,12 +423,45 @@ public:
         check(kde_ers_refined_depth_host(h_, stream_, &p));
         return const_cast<float*>(p);
     }
+    // ---- viewer members (EdgeRefinedSuperpixel.h:27-29, .cpp:70-147); host side ----
+    // refined depth on the reference's ramp over 3000 mm (`max_depth` is ignored there too, .cpp:79-80); then, except in the
+    // last row / column: depth == 0 black, segment borders and label -100 white
+    HostImage8UC3& getSegmentedImage(const int max_depth)
+    {
+        (void)max_depth;
+        const float* depth = getRefinedDepth_Host();
+        const int32_t* labels = getRefinedLabels_Host();
+        if (segmentedImage.rows != Height) segmentedImage = HostImage8UC3(Height, Width);
+        viewers::render_depth(depth, 3000.0f, false, 0.0f, segmentedImage);
+        for (int y = 0; y + 1 < Height; y++)
+            for (int x = 0; x + 1 < Width; x++) {
+                const size_t q = static_cast<size_t>(y) * Width + x;
+                if (depth[q] == 0.0f) segmentedImage.set(y, x, 0, 0, 0);
+                if (labels[q] != labels[q + Width] || labels[q] != labels[q + 1] || labels[q] == -100) segmentedImage.set(y, x, 255, 255, 255);
+            }
+        return segmentedImage;
+    }
+    template <class ImageLike>
+    HostImage8UC3& getSegmentedImage(const ImageLike& input_host)
+    {
+        if (SegmentedColor.rows != Height) SegmentedColor = HostImage8UC3(Height, Width);
+        viewers::copy_from(input_host, SegmentedColor);
+        viewers::mark_label_borders(getRefinedLabels_Host(), SegmentedColor);
+        return SegmentedColor;
+    }
+    HostImage8UC3& getRandomColorImage()
+    {
+        if (SegmentedRandomColor.rows != Height) SegmentedRandomColor = HostImage8UC3(Height, Width);
+        viewers::render_random_colours(getRefinedLabels_Host(), SegmentedRandomColor);
+        return SegmentedRandomColor;
+    }
     void setStream(void* hip_stream) { stream_ = hip_stream; }
 
 private:
     int Width, Height;
     kde_ers* h_ = nullptr;
     void* stream_ = nullptr;
+    HostImage8UC3 segmentedImage, SegmentedColor, SegmentedRandomColor;
 };
 
 // ------------------------------------------------------------------------------------------------

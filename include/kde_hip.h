@@ -208,6 +208,8 @@ int kde_dasp_centers_device(kde_dasp* h, kde_float3** out);
 int kde_dasp_ld_device(kde_dasp* h, kde_label_distance** out);
 /* Labels_Host: refreshed by a blocking copy like DepthAdaptiveSuperpixel.cu:587, but lazily */
 int kde_dasp_labels_host(kde_dasp* h, void* stream, const int32_t** out);
+/* meanData_Host: rows*cols records, refreshed by a blocking copy as the viewers do it (SuperpixelSegmentation.cpp:97) */
+int kde_dasp_mean_host(kde_dasp* h, void* stream, const kde_superpixel** out, int* count);
 
 /* ============================================================================================
  * EdgeRefinedSuperpixel — EdgeRefinedSuperpixel/EdgeRefinedSuperpixel.{h,cpp,cu}

@@ -94,6 +94,7 @@ SIGNATURES = {
     "kde_dasp_mean_device": (_i, [_vp, _pp]),
     "kde_dasp_centers_device": (_i, [_vp, _pp]),
     "kde_dasp_ld_device": (_i, [_vp, _pp]),
+    "kde_dasp_mean_host": (_i, [_vp, _vp, _pp, C.POINTER(_i)]),
     "kde_dasp_labels_host": (_i, [_vp, _vp, _pp]),
     "kde_ers_create": (_i, [_pp, _i, _i]),
     "kde_ers_destroy": (_i, [_vp]),

@@ -167,6 +167,10 @@ struct CalcDivs {          // divisions of the assignment step by multiplication
 // stalls the SIMD for ~20 cycles (tools/valu_microbench: "1 v_cmp + 2 v_cndmask (vcc)" 3.2-6.8 ns per instruction against
 // 1.3 with one other VALU instruction between them and 1.7 in the VOP3 encoding; profiles/r04_valu_microbench_vcc.txt).
 // The argmin update therefore keeps its condition in an SGPR pair and selects with the VOP3 form: same results, no stall.
+// (A 64-bit SGPR pair is the condition of a 64-wide wavefront: this library is built for gfx950 only, see the Makefile.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "dasp_kernels.hip: the SGPR-pair conditions below assume gfx950 (wave64); build with --offload-arch=gfx950"
+#endif
 __device__ __forceinline__ uint64_t lt_mask(float x, float y)
 {
     uint64_t m;

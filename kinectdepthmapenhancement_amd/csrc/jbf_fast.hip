@@ -724,8 +724,8 @@ const Variant kVariants[] = {
     KS(19, 1, 32, 8, false), KS(19, 2, 32, 8, false), V(19, 2, 16, 16, false), V(19, 1, 32, 8, false),
     KN(19, 1, 16, 16, false),
     // r04: the other windows the ABI accepts (kde_jbf_params.window_size is a run-time argument in the reference,
-    // JointBilateralFilter.cu:10,18-19) up to the widest whose log2(S) table fits the kernel-argument block.  Same kernel
-    // template, vector loader; the pass-1 arguments stay in registers at window 3 and are recomputed from window 9 on.
+    // JointBilateralFilter.cu:10,18-19).  Up to window 21 the log2(S) table travels in the kernel-argument block; windows 23-31
+    // (further down) read it from a device table.  Same kernel template, vector loader; the pass-1 arguments stay in registers at window 3 and are recomputed from window 9 on.
     // First listed = built-in choice (tools/sweep_jbf.py, profiles/r04_sweep_k1_windows.log)
     K(3, 1, 16, 16, true),   K(3, 2, 16, 16, true),
     K(9, 2, 16, 16, false),  K(9, 1, 16, 16, false),

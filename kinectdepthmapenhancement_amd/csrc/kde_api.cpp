@@ -621,6 +621,7 @@ struct kde_dasp {
     DevBuf<kde_float3> centers;          // superpixelCenters_Device     [max_batch][rows*cols]
     DevBuf<float> intr;                  // intrinsicDevice
     PinnedBuf<int32_t> labels_host;      // Labels_Host
+    PinnedBuf<kde_superpixel> mean_host; // meanData_Host
     // Set by the pipeline objects (RGBF / SPDSR) for their PRIVATE segmenters: the analyzeClusters that
     // follows the last calculateLD only refreshes mean/centres, which nothing reads before the next
     // Segmentation re-samples them (DepthAdaptiveSuperpixel.cu:576-586) and which the pipelines do not expose.
@@ -741,6 +742,20 @@ extern "C" int kde_dasp_labels_host(kde_dasp* h, void* stream, const int32_t** o
     KDE_HIP_TRY(hipMemcpyAsync(h->labels_host.p, h->labels.p, px * sizeof(int32_t), hipMemcpyDeviceToHost, as_stream(stream)));
     KDE_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     *out = h->labels_host.p;
+    return KDE_OK;
+}
+
+extern "C" int kde_dasp_mean_host(kde_dasp* h, void* stream, const kde_superpixel** out, int* count)
+{
+    KDE_REQUIRE(h && out && count, "kde_dasp_mean_host: null argument");
+    KDE_ON_DEVICE(h, "kde_dasp_mean_host");
+    KDE_REQUIRE(h->set, "kde_dasp_mean_host: SetParametor has not been called");
+    const size_t nc = (size_t)h->g.rows * h->g.cols;
+    KDE_TRY(h->mean_host.ensure(nc));
+    KDE_HIP_TRY(hipMemcpyAsync(h->mean_host.p, h->mean.p, nc * sizeof(kde_superpixel), hipMemcpyDeviceToHost, as_stream(stream)));
+    KDE_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    *out = h->mean_host.p;
+    *count = (int)nc;
     return KDE_OK;
 }
 
