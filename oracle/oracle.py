@@ -94,11 +94,48 @@ class Env:
         return Env(flags=g[prefix + "_flags"], lo=g[prefix + "_lo"], hi=g[prefix + "_hi"])
 
 
-def parity_check(got, ref, env=None, rtol=1e-4):
+def deviation_census(got, ref, flagged=None, grid=None, rtol=1e-4):
+    """How far an output is from the float32 restatement END TO END, pixel by pixel, whatever class the pixel is in (the
+    number north_star's "within 1e-4 of the reference path" asks for):
+      n_rel_gt_rtol                 pixels where both hold a number and differ by more than rtol (relative to the float32 value)
+      n_rel_gt_rtol_flagged / _unflagged   the same, split by `flagged` (the envelope's BAND / COND classes); unflagged must be 0
+      n_zero_mask_differs           pixels where exactly one of the two is 0 (= n_gained_zero + n_lost_zero: the output is 0 where
+                                    the restatement holds a value / holds a value where the restatement is 0), and its flagged split
+      n_nan_mask_differs            pixels where exactly one of the two is NaN
+      max_rel, rel_p99_flagged      the largest deviation, and the 99th percentile over the flagged pixels
+      grid_*                        the same counts over `grid` (oracle.Stage.GRID: results on the float32 denormal grid)."""
+    got = np.asarray(got, np.float32)
+    ref = np.asarray(ref, np.float32).reshape(got.shape)
+    fl = np.zeros(got.shape, bool) if flagged is None else np.asarray(flagged, bool).reshape(got.shape)
+    nan_ref, nan_got = np.isnan(ref), np.isnan(got)
+    num = ~nan_ref & ~nan_got
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.where(num & (ref != 0), np.abs(got.astype(np.float64) - ref.astype(np.float64)) / np.abs(ref.astype(np.float64)), 0.0)
+    far = num & (ref != 0) & (got != 0) & (rel > rtol)
+    gained = num & (ref != 0) & (got == 0)
+    lost = num & (ref == 0) & (got != 0)
+    zdiff = gained | lost
+    out = {"n": int(got.size), "rtol": rtol,
+           "n_rel_gt_rtol": int(far.sum()), "n_rel_gt_rtol_flagged": int((far & fl).sum()), "n_rel_gt_rtol_unflagged": int((far & ~fl).sum()),
+           "n_zero_mask_differs": int(zdiff.sum()), "n_gained_zero": int(gained.sum()), "n_lost_zero": int(lost.sum()),
+           "n_zero_mask_differs_flagged": int((zdiff & fl).sum()), "n_zero_mask_differs_unflagged": int((zdiff & ~fl).sum()),
+           "n_nan_mask_differs": int((nan_ref != nan_got).sum()),
+           "frac_rel_gt_rtol": float(far.sum() / max(1, got.size)), "frac_zero_mask_differs": float(zdiff.sum() / max(1, got.size)),
+           "max_rel": float(rel[far].max()) if far.any() else float(rel.max()) if rel.size else 0.0,
+           "rel_p99_flagged": float(np.percentile(rel[fl & num & (got != 0)], 99)) if (fl & num & (got != 0)).any() else 0.0}
+    if grid is not None:
+        g = np.asarray(grid, bool).reshape(got.shape)
+        out.update(grid_pixels=int(g.sum()), grid_rel_gt_rtol=int((far & g).sum()), grid_zero_mask_differs=int((zdiff & g).sum()),
+                   grid_max_rel=float(rel[far & g].max()) if (far & g).any() else 0.0)
+    return out
+
+
+def parity_check(got, ref, env=None, rtol=1e-4, grid=None):
     """The parity bar of this repo, every pixel checked (used by tests/conftest.py, smoke() and bench.py's `verified`):
       * unflagged pixels (all pixels when env is None): identical zero / NaN mask, <= rtol relative to the float32 value;
       * flagged pixels (env.flagged): inside [lo, hi] widened by rtol, or 0 / NaN where the envelope admits that.
-    -> dict with the boolean map `bad` and the statistics the tests print."""
+    -> dict with the boolean map `bad`, the statistics the tests print, and `census`: deviation_census(got, ref, flagged, grid),
+    the end-to-end distance from the float32 value counted over ALL pixels."""
     got = np.asarray(got, np.float32)
     ref = np.asarray(ref, np.float32)
     assert got.shape == ref.shape
@@ -127,7 +164,7 @@ def parity_check(got, ref, env=None, rtol=1e-4):
         ok = np.where(nan_got, nan_ok, np.where(got == 0, zero_ok, inside))
         bad_env = flagged & ~ok
         band, cond = int(((fl & Env.BAND) != 0).sum()), int(((fl & Env.COND) != 0).sum())
-    return {"bad": bad_nan | bad_zero | bad_rel | bad_env, "rel": rel,
+    return {"bad": bad_nan | bad_zero | bad_rel | bad_env, "rel": rel, "census": deviation_census(got, ref, flagged, grid, rtol),
             "n": int(ref.size), "flagged": int(flagged.sum()), "band": band, "cond": cond,
             "bad_nan": int(bad_nan.sum()), "bad_zero": int(bad_zero.sum()), "bad_rel": int(bad_rel.sum()),
             "outside_envelope": int(bad_env.sum()),
@@ -244,7 +281,7 @@ def stage_check(final, st: Stage, rtol=1e-4):
     ndec = int((band & ~grid).sum())            # interval-checked because a tap is ON a decision (not the denormal-grid class)
     expect_avg = have_avg & ~band & ~mismatch   # every strict pixel that has an average must have had it compared
     q = lambda a, m, pc: float(np.percentile(a[m], pc)) if m.any() else 0.0
-    return {"bad": bad, "rel": rel, "avg_unchecked": expect_avg & ~cmp_avg,
+    return {"bad": bad, "rel": rel, "avg_unchecked": expect_avg & ~cmp_avg, "grid_map": grid, "band_map": band,
             "n": int(got.size), "band": nb, "grid": int(grid.sum()), "band_decision": ndec,
             "band_frac": nb / max(1, got.size), "band_decision_frac": ndec / max(1, got.size), "grid_frac": int(grid.sum()) / max(1, got.size),
             "avg_checked_of_strict": float((cmp_avg & expect_avg).sum() / max(1, int(expect_avg.sum()))),

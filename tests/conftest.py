@@ -71,7 +71,11 @@ def pytest_terminal_summary(terminalreporter):
             terminalreporter.write_line(line)
 
 
-def assert_depth_close(got, ref, rtol=1e-4, ill=None, max_bad=0, what="depth", max_flagged=None):
+CENSUS_LOG = {}     # what -> deviation census (oracle.deviation_census); tools/census_report.py reads the same function
+
+
+def assert_depth_close(got, ref, rtol=1e-4, ill=None, max_bad=0, what="depth", max_flagged=None, max_far=None, max_zero_diff=None,
+                       grid=None):
     """HIP vs oracle bar for float depth maps.  EVERY pixel is checked:
       * pixels the oracle's envelope does not flag (and all pixels when no envelope is given): identical zero / NaN
         mask and <= rtol relative error against the float32 restatement;
@@ -79,13 +83,28 @@ def assert_depth_close(got, ref, rtol=1e-4, ill=None, max_bad=0, what="depth", m
         average beyond 5e-5): the value must lie inside the envelope [lo, hi] of binary64 evaluations of the same
         formula (widened by rtol), or be 0 / NaN where the envelope admits that.
     Returns the max relative error on unflagged pixels; per-class counts and the max error on flagged pixels are
-    logged (PARITY_LOG) and `max_flagged` bounds the flagged fraction."""
+    logged (PARITY_LOG) and `max_flagged` bounds the flagged fraction.
+    The END-TO-END distance from the float32 value is counted over all pixels (oracle.deviation_census) and bounded:
+    `max_far` = ceiling on the fraction of pixels more than rtol away from the float32 value, `max_zero_diff` = ceiling on the
+    fraction whose zero mask differs; `grid` (Stage.GRID map) adds the same counts for the denormal-grid class."""
     got = np.asarray(got, np.float32)
     ref = np.asarray(ref, np.float32)
     if ill is not None and not hasattr(ill, "flagged"):
         raise TypeError("assert_depth_close needs an oracle.Env (flags + envelope), not a bare flag map")
     from oracle.oracle import parity_check
-    r = parity_check(got, ref, ill, rtol)
+    r = parity_check(got, ref, ill, rtol, grid=grid)
+    c = r["census"]
+    CENSUS_LOG[what] = c
+    if ill is not None or max_far is not None or max_zero_diff is not None:
+        PARITY_LOG.append(f"{what} [census vs float32]: > {rtol:g} away {c['n_rel_gt_rtol']} ({c['frac_rel_gt_rtol']:.2e}; unflagged "
+                          f"{c['n_rel_gt_rtol_unflagged']}), zero mask differs {c['n_zero_mask_differs']} ({c['frac_zero_mask_differs']:.2e}: "
+                          f"gained {c['n_gained_zero']}, lost {c['n_lost_zero']}), NaN mask differs {c['n_nan_mask_differs']}, max rel "
+                          f"{c['max_rel']:.2e}, p99 over flagged {c['rel_p99_flagged']:.2e}"
+                          + (f"; GRID {c['grid_pixels']} px: > rtol {c['grid_rel_gt_rtol']}, zero mask {c['grid_zero_mask_differs']}" if grid is not None else ""))
+    if max_far is not None:
+        assert c["frac_rel_gt_rtol"] <= max_far, f"{what}: {c['frac_rel_gt_rtol']:.3e} of the pixels are more than {rtol:g} from the float32 value (> {max_far})"
+    if max_zero_diff is not None:
+        assert c["frac_zero_mask_differs"] <= max_zero_diff, f"{what}: zero mask differs on {c['frac_zero_mask_differs']:.3e} of the pixels (> {max_zero_diff})"
     if ill is not None:
         frac = r["flagged"] / max(1, r["n"])
         PARITY_LOG.append(f"{what}: {r['n']} px, flagged {r['flagged']} ({frac:.2e}: band {r['band']}, cond {r['cond']}), "
