@@ -273,9 +273,14 @@ __device__ __forceinline__ f2 pk_mul_clamp(f2 a, f2 b)
 // below share one kernel, and without it the window-19 instance grew from 131 to 182 VGPRs (3 -> 2 waves per SIMD)
 // (windows >= 23: at least 3 waves per SIMD, i.e. <= 168 VGPRs -- without the bound the instances without the colour rule
 //  came out at 228 / 248 registers, 2 waves per SIMD)
-template <int WIN, int NP, int BX, int BY, bool CACHE, bool CSKIP, bool VL, bool ELIDE_ON = true>
-__global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 23 ? 3 : 1))) void jbf_pk_kernel(const FastArgs a)
+// CR = window rows whose pass-1 arguments are kept for pass 2 (CACHE: all of them, the windows <= 7; 0: recomputed).  0 < CR < WIN
+// is r05's partial form for windows 9..13: the first CR rows are unrolled and their arguments stay in registers -- with two
+// waves per SIMD asked for, the allocator has 256 registers per lane and parks what does not fit the VGPRs in AccVGPRs
+// (v_accvgpr_write / _read, 2-cycle class) -- the remaining rows run the recomputing loop.
+template <int WIN, int NP, int BX, int BY, bool CACHE, bool CSKIP, bool VL, bool ELIDE_ON = true, int CR = (CACHE ? WIN : 0)>
+__global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 23 ? 3 : ((CR > 0 && !CACHE) ? 2 : 1)))) void jbf_pk_kernel(const FastArgs a)
 {
+    static_assert(CR >= 0 && CR <= WIN && (!CACHE || CR == WIN), "cached rows");
     constexpr int R = WIN / 2;
     constexpr int PX = 2 * NP;
     constexpr int NT = BX * BY;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 2
 
     f2 kc2 = bcast(a.kc);
     asm volatile("" : "+v"(kc2));   // keep kc in a VGPR pair: the fma's only scalar operand is then the log2(S) SGPR pair
-    f2 arg[CACHE ? WIN * WIN * NP : 1];
+    f2 arg[CR > 0 ? CR * WIN * NP : 1];
     f2 wsum[NP], wgt[NP];
 #pragma unroll
     for (int pp = 0; pp < NP; pp++) wsum[pp] = wgt[pp] = bcast(0.0f);
@@ -536,7 +541,8 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 2
         return f2{dp[pp].y, dp[pp + HALF].x};
     };
 
-    auto pass1_row = [&](auto cs_tag, int i) {
+    auto pass1_row = [&](auto cs_tag, auto keep_tag, int i) {
+        constexpr bool KEEP = decltype(keep_tag)::value;
         f2 dp[SEGP], vp[SEGP];
         u2 cp[SEGP], np[SEGP];
         const int rb = (ty + i) * P + sx;
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 2
 #pragma unroll
             for (int u = 0; u < WIN; u++) {
                 const f2 a1 = unit_arg(cs_tag, cp, np, pp, i, u);
-                if (CACHE) arg[(i * NP + pp) * WIN + u] = a1;
+                if constexpr (KEEP) arg[(i * NP + pp) * WIN + u] = a1;
                 const f2 f = f2{__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
                 wsum[pp] = pk_fma(unit_depth(dp, pp, u), f, wsum[pp]);
                 wgt[pp] = pk_fma(unit_depth(vp, pp, u), f, wgt[pp]);
@@ -561,8 +567,9 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 2
     };
     f2 c2[NP], num[NP], den[NP];
 
-    auto pass2_row = [&](auto cs_tag, auto ds_tag, int i) {
+    auto pass2_row = [&](auto cs_tag, auto ds_tag, auto keep_tag, int i) {
         constexpr bool DS = decltype(ds_tag)::value;
+        constexpr bool KEEP = decltype(keep_tag)::value;
         f2 dp[SEGP], vp[SEGP];
         u2 cp[SEGP], np[SEGP];
         const int rb = (ty + i) * P + sx;
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 2
         for (int m = 0; m < SEGP; m++) {
             dp[m] = ALIGNED ? *reinterpret_cast<const f2*>(&s_d[rb + 2 * m]) : f2{s_d[rb + 2 * m], s_d[rb + 2 * m + 1]};
             vp[m] = pk_add_clamp(dp[m], dp[m]);
-            if (!CACHE) {
+            if constexpr (!KEEP) {
                 cp[m] = ALIGNED ? *reinterpret_cast<const u2*>(&s_c[rb + 2 * m]) : u2{s_c[rb + 2 * m], s_c[rb + 2 * m + 1]};
                 np[m] = ALIGNED ? *reinterpret_cast<const u2*>(&s_n[rb + 2 * m]) : u2{s_n[rb + 2 * m], s_n[rb + 2 * m + 1]};
             }
@@ -579,7 +586,9 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 2
         for (int pp = 0; pp < NP; pp++) {
 #pragma unroll
             for (int u = 0; u < WIN; u++) {
-                const f2 a1 = CACHE ? arg[(i * NP + pp) * WIN + u] : unit_arg(cs_tag, cp, np, pp, i, u);
+                f2 a1;
+                if constexpr (KEEP) a1 = arg[(i * NP + pp) * WIN + u];
+                else a1 = unit_arg(cs_tag, cp, np, pp, i, u);
                 const f2 dq = unit_depth(dp, pp, u);
                 const f2 t = (dq - c2[pp]) * bcast(a.sd);    // subtract first: see the scalar kernel
                 f2 a2;
@@ -597,13 +606,11 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 2
     };
     // both passes, specialised on which Q1 rules this tile needs
     auto run = [&](auto cs_tag, auto ds_tag) {
-        if (CACHE) {
+        // rows [0, CR): unrolled, arguments kept; rows [CR, WIN): the recomputing loop
 #pragma unroll
-            for (int i = 0; i < WIN; i++) pass1_row(cs_tag, i);
-        } else {
+        for (int i = 0; i < CR; i++) pass1_row(cs_tag, std::true_type{}, i);
 #pragma unroll 1
-            for (int i = 0; i < WIN; i++) pass1_row(cs_tag, i);
-        }
+        for (int i = CR; i < WIN; i++) pass1_row(cs_tag, std::false_type{}, i);
 #pragma unroll
         for (int pp = 0; pp < NP; pp++) {
             // window averages (wgt == 0 handled at the store); v_rcp_f32 is 1 ulp, the same order as the
@@ -611,13 +618,10 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 2
             c2[pp] = wsum[pp] * f2{__builtin_amdgcn_rcpf(wgt[pp].x), __builtin_amdgcn_rcpf(wgt[pp].y)};
             num[pp] = den[pp] = bcast(0.0f);
         }
-        if (CACHE) {
 #pragma unroll
-            for (int i = 0; i < WIN; i++) pass2_row(cs_tag, ds_tag, i);
-        } else {
+        for (int i = 0; i < CR; i++) pass2_row(cs_tag, ds_tag, std::true_type{}, i);
 #pragma unroll 1
-            for (int i = 0; i < WIN; i++) pass2_row(cs_tag, ds_tag, i);
-        }
+        for (int i = CR; i < WIN; i++) pass2_row(cs_tag, ds_tag, std::false_type{}, i);
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
@@ -655,7 +659,7 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 2
     }
 }
 
-template <int WIN, int NP, int BX, int BY, bool CACHE, bool VL, bool ELIDE_ON = true>
+template <int WIN, int NP, int BX, int BY, bool CACHE, bool VL, bool ELIDE_ON = true, int CR = (CACHE ? WIN : 0)>
 int launch_pk_variant(const JbfLaunch& l, const FastArgs& fa, bool cskip, hipStream_t s)
 {
     FastArgs a = fa;
@@ -666,9 +670,9 @@ int launch_pk_variant(const JbfLaunch& l, const FastArgs& fa, bool cskip, hipStr
     a.div_tx = make_fastdiv24((uint32_t)a.tiles_x, (uint64_t)a.tiles_x * a.tiles_y);
     if (blocks > 0x7fffffffLL) return fail(KDE_ERR_INVALID, "jbf: batch too large for one launch");
     if (cskip)
-        hipLaunchKernelGGL((jbf_pk_kernel<WIN, NP, BX, BY, CACHE, true, VL, ELIDE_ON>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
+        hipLaunchKernelGGL((jbf_pk_kernel<WIN, NP, BX, BY, CACHE, true, VL, ELIDE_ON, CR>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
     else
-        hipLaunchKernelGGL((jbf_pk_kernel<WIN, NP, BX, BY, CACHE, false, VL, ELIDE_ON>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
+        hipLaunchKernelGGL((jbf_pk_kernel<WIN, NP, BX, BY, CACHE, false, VL, ELIDE_ON, CR>), dim3((unsigned)blocks), dim3(BX * BY), 0, s, a);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }
@@ -707,6 +711,9 @@ struct Variant {
     {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v1", WIN, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, false>}
 #define KN(WIN, NP, BX, BY, CACHE) \
     {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-" #CACHE "-v4-noelide", WIN, true, &launch_pk_variant<WIN, NP, BX, BY, CACHE, true, false>}
+// r05 experiment: the first CR window rows keep their pass-1 arguments (VGPRs + AccVGPRs at two waves per SIMD)
+#define KC(WIN, NP, BX, BY, CR) \
+    {"w" #WIN "-pk" #NP "-" #BX "x" #BY "-keep" #CR "-v4", WIN, true, &launch_pk_variant<WIN, NP, BX, BY, false, true, true, CR>}
 const Variant kVariants[] = {
     // the FIRST variant listed for a window is the built-in choice (interleaved A/B sweep on MI355X,
     // profiles/r03_sweep_k1_variants.log); the others stay selectable for the tile sweep of BASELINE config 3.
@@ -735,12 +742,16 @@ const Variant kVariants[] = {
     K(21, 1, 16, 16, false), K(21, 2, 16, 16, false),
     // windows 23..31: the log2(S) table no longer fits the argument block and comes from a device copy (FastArgs::tab_dev)
     K(23, 1, 16, 16, false), K(25, 1, 16, 16, false), K(27, 1, 16, 16, false), K(29, 1, 16, 16, false), K(31, 1, 16, 16, false),
+    // r05: part of the pass-1 arguments kept in VGPRs / AccVGPRs at two waves per SIMD
+    KC(9, 1, 16, 16, 9), KC(9, 1, 16, 16, 5), KC(9, 2, 16, 16, 4), KC(11, 1, 16, 16, 5), KC(11, 1, 16, 16, 7), KC(11, 2, 16, 16, 3),
+    KC(13, 1, 16, 16, 4), KC(13, 1, 16, 16, 6),
 };
 static_assert(sizeof(FastArgs) <= 4096, "FastArgs is passed by value as the kernel-argument block");
 #undef V
 #undef K
 #undef KS
 #undef KN
+#undef KC
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 }  // namespace

@@ -25,8 +25,14 @@ BENCH = dict(window=11, ss=3.0, cs=7.65, ds=20.0)        # bench.py's headline p
 
 # ceilings of the end-to-end census against the float32 restatement: (fraction of pixels > 1e-4 away, fraction whose zero mask
 # differs, fraction flagged by the envelope) = about 1.5 x what round 5 measured (profiles/r05_census.txt)
-CENSUS = {"config2": (None, None, 0.05), "config3": (None, None, 0.08), "config4": (None, None, 0.08),
-          "config5_jbf": (None, None, 0.05), "config5_rgbf": (None, None, 0.05)}
+# measured:        > 1e-4 away            zero mask differs   flagged
+#   config 2        3 px  (9.8e-06)        0                   2.75e-02
+#   config 3        55 px (2.7e-05)        0                   1.74e-02      (47 of the 55 are GRID pixels)
+#   config 4        1-2 px per frame       0                   1.5-2.2e-02
+#   config 5 JBF    0                      0                   2.06e-03
+#   config 5 RGBF   1 px  (4.8e-07)        0                   4.96e-04
+CENSUS = {"config2": (2e-5, 0.0, 0.04), "config3": (4e-5, 0.0, 0.026), "config4": (1.3e-5, 0.0, 0.033),
+          "config5_jbf": (2e-6, 0.0, 0.0031), "config5_rgbf": (2e-6, 0.0, 7.5e-4)}
 
 
 @pytest.fixture(scope="module")
