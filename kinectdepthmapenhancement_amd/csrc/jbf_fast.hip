@@ -27,6 +27,7 @@
 #include "kde_internal.h"
 #include "kde_device_math.h"
 
+#include <cstddef>
 #include <type_traits>
 
 namespace kde {
@@ -274,9 +275,9 @@ __device__ __forceinline__ f2 pk_mul_clamp(f2 a, f2 b)
 // (windows >= 23: at least 3 waves per SIMD, i.e. <= 168 VGPRs -- without the bound the instances without the colour rule
 //  came out at 228 / 248 registers, 2 waves per SIMD)
 // CR = window rows whose pass-1 arguments are kept for pass 2 (CACHE: all of them, the windows <= 7; 0: recomputed).  0 < CR < WIN
-// is r05's partial form for windows 9..13: the first CR rows are unrolled and their arguments stay in registers -- with two
-// waves per SIMD asked for, the allocator has 256 registers per lane and parks what does not fit the VGPRs in AccVGPRs
-// (v_accvgpr_write / _read, 2-cycle class) -- the remaining rows run the recomputing loop.
+// is r05's partial form for windows 9..13: the first CR rows are unrolled and their arguments stay in registers (two waves per
+// SIMD asked for: 256 registers per lane), the remaining rows run the recomputing loop.  Measured slower (see kVariants): only
+// the measurement build instantiates it.
 template <int WIN, int NP, int BX, int BY, bool CACHE, bool CSKIP, bool VL, bool ELIDE_ON = true, int CR = (CACHE ? WIN : 0)>
 __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 23 ? 3 : ((CR > 0 && !CACHE) ? 2 : 1)))) void jbf_pk_kernel(const FastArgs a)
 {
@@ -529,6 +530,12 @@ __global__ __launch_bounds__(BX* BY) __attribute__((amdgpu_waves_per_eu(WIN >= 2
             // compiler issue per-lane global_load_dwordx4 and hold the pairs in VGPRs: 248 instead of ~150 registers)
             typedef const f2 __attribute__((address_space(4)))* cf2p;
             lsj = *(cf2p)(uintptr_t)(a.tab_dev + (i * WIN + u) * 2);
+        } else if constexpr (CR > 0 && !CACHE) {
+            // the partial-keep instances: read the pair straight from the kernel-argument segment (the argument block IS
+            // FastArgs).  Through `a.tab` the compiler copied the whole 3.6 KB block to scratch in the instances with the colour rule.
+            typedef const f2 __attribute__((address_space(4)))* cf2p;
+            typedef const char __attribute__((address_space(4)))* ccp;
+            lsj = *(cf2p)((ccp)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FastArgs, tab) + (size_t)((i * WIN + u) * 2) * sizeof(float));
         } else {
             lsj = *reinterpret_cast<const f2*>(&a.tab[(i * WIN + u) * 2]);
         }
@@ -742,9 +749,16 @@ const Variant kVariants[] = {
     K(21, 1, 16, 16, false), K(21, 2, 16, 16, false),
     // windows 23..31: the log2(S) table no longer fits the argument block and comes from a device copy (FastArgs::tab_dev)
     K(23, 1, 16, 16, false), K(25, 1, 16, 16, false), K(27, 1, 16, 16, false), K(29, 1, 16, 16, false), K(31, 1, 16, 16, false),
-    // r05: part of the pass-1 arguments kept in VGPRs / AccVGPRs at two waves per SIMD
+#ifdef KDE_AB_SWITCHES
+    // r05: part of the pass-1 arguments kept in registers at two waves per SIMD.  Bit-identical, and
+    // SLOWER at windows 11 and 13 (+5 .. +12 %), a wash at window 9 (-0.6 % on 64 x 640x480, +1.6 .. +5 % at 1080p):
+    // profiles/r05_sweep_k1_variants.log (tools/ab_k1_keep.py).  The allocator keeps everything in the 256 architectural
+    // VGPRs (agpr_count 0: on gfx950 the file is unified, AccVGPRs would only add capacity at ONE wave per SIMD), so what is
+    // bought is 8 of 20 issue slots on the kept units and what is paid is the occupancy (2 instead of 4-6 waves per SIMD:
+    // the v_exp_f32 / LDS latency is no longer covered) and 2-3 x the code per body.  Measurement build only; K1 is closed.
     KC(9, 1, 16, 16, 9), KC(9, 1, 16, 16, 5), KC(9, 2, 16, 16, 4), KC(11, 1, 16, 16, 5), KC(11, 1, 16, 16, 7), KC(11, 2, 16, 16, 3),
     KC(13, 1, 16, 16, 4), KC(13, 1, 16, 16, 6),
+#endif
 };
 static_assert(sizeof(FastArgs) <= 4096, "FastArgs is passed by value as the kernel-argument block");
 #undef V
