@@ -28,8 +28,9 @@ launches of one (kernel name, grid size); derived figures follow /opt/skills/gui
                                                instructions) / 1024 / cycles -- what no mix estimate can fall below
                           valu_ns_frac       = the same with the wall-time costs over End - Start of the launch (the micro-benchmark's
                                                pure streams run at a lower clock than a kernel's mix: can read a few % high)
-                        valu_cycles_frac <= 1 by construction (the costs are the cheapest each opcode gets at any occupancy); it is
-                        the "fraction of the VALU-issue ceiling" DESIGN.md quotes per kernel.
+                        valu_cycles_frac is an ESTIMATE (the class costs are measured costs of pure instruction streams, rounded to
+                        2 / 4 / 8 cycles -- not lower bounds: dual issue or a different clock can move it past 1); it is the
+                        "fraction of the VALU-issue ceiling" DESIGN.md quotes per kernel.
   waves_per_simd      = SQ_WAVE_CYCLES x 4 / (1024 x cycles)                    (mean resident waves per SIMD)
   lds_conflict_frac   = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 `--algo` optionally maps a kernel-name substring to algorithmic bytes per launch so that traffic ratios are in the file."""

@@ -8,7 +8,7 @@ A model that books 4 cycles for every instruction is therefore not a ceiling (SQ
 kernels).  This module prices a kernel by what its own instruction stream costs:
 
     bare_ns(kernel) = sum over VALU mnemonics m of  n_m x cost_ns(m)          per wave
-    ceiling fraction = bare_ns x waves / 1024 SIMDs / launch time             (<= 1: the costs are the cheapest each opcode gets)
+    ceiling fraction = bare_ns x waves / 1024 SIMDs / launch time             (an estimate: measured class costs, not lower bounds)
 
 n_m comes from the kernel's gfx950 assembly (compiled here with the library's own flags): the static histogram, with the bodies
 of loops weighted by ONE common trip factor x chosen so that the total matches the hardware's dynamic count per wave
