@@ -214,11 +214,30 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
     // that each XCD works through a contiguous band of the tile list and horizontally adjacent tiles -- which share their
     // halo columns and, being only 96 bytes wide, their 128-byte lines -- meet in ONE L2 (KDE_K0_BAND_WALK, see launch_presmooth)
     auto tile_of = [&](int L) { return a.band_walk ? (int)xcd_band_id((unsigned)L, (unsigned)total) : L; };
+    // band_walk == 2 ("run walk", r05): XCD bands as above, but a workgroup takes RUNS of kRun horizontally adjacent tiles one
+    // after the other instead of every (workgroups per XCD)-th tile.  Four 32-pixel tiles are 384 bytes = three 128-byte lines
+    // of a row: inside a run every line a tile shares with its neighbour is re-read by the SAME workgroup a moment later (an L2
+    // hit, never two workgroups queueing on one line at the same time, which is what made the plain band walk slower on large
+    // batches), and concurrently running workgroups of an XCD only share the one halo line between two runs.
+    // -> this workgroup's it-th tile, or -1 when it has none left (all scalars)
+    constexpr int kRun = 4;
+    auto tile_index = [&](int it) -> int {
+        if (a.band_walk != 2) {
+            const long long L = (long long)blockIdx.x + (long long)it * gridDim.x;
+            return L < total ? tile_of((int)L) : -1;
+        }
+        const unsigned xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u;
+        const unsigned per = (unsigned)total / 8u, rem = (unsigned)total % 8u;
+        const unsigned start = xcd * per + (xcd < rem ? xcd : rem), len = per + (xcd < rem ? 1u : 0u);
+        const unsigned wgs = (gridDim.x + 7u - xcd) / 8u;                 // workgroups that run on this XCD
+        const unsigned pos = (unsigned)kRun * (slot + ((unsigned)it / kRun) * wgs) + (unsigned)it % kRun;
+        return pos < len ? (int)(start + pos) : -1;
+    };
     // (frame, tile row, tile column) of linear tile index L: computed ONCE per tile (when it is prefetched) and carried to
     // the iteration that computes it; the two divisions are multiplications (fastdiv24, exact for < 2^24 tiles)
     struct TileAt { int frame_i, tyi, txi; };
-    auto tile_at = [&](int L) {
-        const uint32_t t = (uint32_t)tile_of(L);
+    auto tile_at = [&](int tile_id) {
+        const uint32_t t = (uint32_t)tile_id;
         const uint32_t f = fastdiv24(t, a.div_tpf);
         const uint32_t tile = t - f * (uint32_t)tiles_per_frame;
         const uint32_t ty_ = fastdiv24(tile, a.div_tx);
@@ -255,11 +274,12 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
 
     uint32_t pre[NSLOT];
     TileAt cur{0, 0, 0};
-    if ((int)blockIdx.x < total) {
-        cur = tile_at(blockIdx.x);
+    int cur_id = tile_index(0);
+    if (cur_id >= 0) {
+        cur = tile_at(cur_id);
         fetch(cur, pre);
     }
-    for (int L = blockIdx.x; L < total; L += gridDim.x) {
+    for (int it = 0; cur_id >= 0; it++) {
         const int frame_i = cur.frame_i;
         const int x0 = cur.txi * kPreTW, y0 = cur.tyi * kPreTH;
         const size_t frame = (size_t)frame_i * a.width * a.height;
@@ -269,8 +289,9 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
         for (int k = 0; k < NSLOT; k++)
             if (stager && sy0 + k * RPP < LH) sc[lds0 + k * RPP * LP] = pre[k] & 0x00ffffffu;     // the 4th byte belongs to the next pixel
         __syncthreads();
-        if (L + (int)gridDim.x < total) {
-            cur = tile_at(L + gridDim.x);
+        cur_id = tile_index(it + 1);
+        if (cur_id >= 0) {
+            cur = tile_at(cur_id);
             fetch(cur, pre);
         }
 
@@ -759,15 +780,18 @@ long long presmooth_resident_blocks(int radius)
     }
 }
 
-// Whether the row-pair kernel walks its tiles in XCD bands.  The walk makes horizontally adjacent tiles (shared halo columns,
-// shared 128-byte lines) meet in one L2; measured inside the chain (tools/ab_k0_band.sh, profiles/r03_ab_k0_band.txt) it pays
-// while a launch's input fits the eight L2s (one 1080p frame 18.2 -> 15.5 us, one 640x480 frame 9.1 -> 8.2 us) and costs on a
-// large batch (64 x 640x480 inside the headline step: 0.103 -> 0.110 ms although the fetched bytes halve; groups of 2 or 4
-// adjacent tiles per XCD inside one moving window of the batch: 0.109 / 0.111 ms) -- neighbouring tiles that stage the same
-// lines at the same time queue on one L2 channel instead of being served by eight.
+// How the row-pair kernel walks its tiles (PreDev::band_walk; tools/ab_k0_walk.sh, profiles/r05_ab_k0_walk.txt):
+//   0  linear: tile t runs on XCD t % 8, so the two tiles that share a 128-byte line (a tile row is 96 bytes) always sit in
+//      different L2s: K0 read 3.04 x its algorithmic bytes on 64 x 640x480 (total traffic 2.03 x);
+//   1  XCD bands: horizontally adjacent tiles meet in one L2 (reads 0.99 x, total 1.02 x) but are staged by DIFFERENT
+//      workgroups at the same time; best while a launch's input fits the eight L2s (one 1080p frame 18.1 vs 19.1 us);
+//   2  XCD bands in runs of four adjacent tiles (384 bytes = three lines) per workgroup: the shared lines are re-read by the
+//      same workgroup a moment later (reads 1.00 x, total 1.05 x); on batches it is as fast as the linear walk inside the
+//      headline step (0.0855 vs 0.0846 ms on 64 x 640x480, within the run-to-run spread) and faster alone / on 1080p batches
+//      (8 x 1080p: 0.0701 vs 0.0721 ms in the step, 0.0649 vs 0.0681 alone) -- at half the HBM traffic.
 static int k0_band_walk(int width, int height, int n)
 {
-    return (long long)width * height * n * 3 <= (32ll << 20) ? 1 : 0;
+    return (long long)width * height * n * 3 <= (32ll << 20) ? 1 : 2;
 }
 
 int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
@@ -787,7 +811,7 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
 #ifdef KDE_AB_SWITCHES
     // measurement build only: KDE_K0_2X2 selects the 2 x 2 form, KDE_K0_BAND_WALK=0/1 forces the walk (tools/ab_k0_band.sh, tools/bench_k0.py)
     old_form = a.radius > 2 || !k0_use_2x2();
-    static const int force = [] { const char* e = KDE_AB_ENV("KDE_K0_BAND_WALK"); return e ? (e[0] != '0' ? 1 : 0) : -1; }();
+    static const int force = [] { const char* e = KDE_AB_ENV("KDE_K0_BAND_WALK"); return e ? (e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1) : -1; }();
     if (force >= 0) d.band_walk = force;
     if (!old_form) {
         d.tiles_x = ceil_div(a.width, kPre22TW);
