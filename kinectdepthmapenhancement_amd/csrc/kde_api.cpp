@@ -1048,6 +1048,8 @@ struct kde_spdsr {
     kde_float3* optimized = nullptr;
     int n_last = 1;
     PinnedBuf<kde_float3> optimized_host;
+    SpdsrResident resident;           // one frame: the 20 sweeps as one LDS-resident cooperative launch
+    ~kde_spdsr() { spdsr_resident_release(&resident); }
 };
 
 extern "C" int kde_spdsr_create_batch(kde_spdsr** out, int width, int height, int max_batch)
@@ -1063,6 +1065,7 @@ extern "C" int kde_spdsr_create_batch(kde_spdsr** out, int width, int height, in
     if (rc == KDE_OK) rc = h->plane_fitted.alloc(px * max_batch);
     if (rc == KDE_OK) rc = h->opt_a.alloc(px * max_batch);
     if (rc == KDE_OK) rc = h->opt_b.alloc(px * max_batch);
+    if (rc == KDE_OK) rc = spdsr_resident_init(&h->resident);
     if (rc != KDE_OK) { delete h; return rc; }
     *out = h;
     return KDE_OK;
@@ -1110,7 +1113,7 @@ extern "C" int kde_spdsr_process_batch(kde_spdsr* h, int n, const float* depth_d
     h->n_last = n;
     return launch_spdsr_plane_projection(h->p.width, h->p.height, n, h->nclusters, h->cluster_nd.p, h->p.ERS->labels_a.p,
                                          h->edge_points.p, h->nxy.p, h->plane_fitted.p, h->opt_a.p, h->opt_b.p, 20,
-                                         &h->optimized, s);
+                                         &h->optimized, &h->resident, s);
 }
 
 extern "C" int kde_spdsr_process(kde_spdsr* h, const float* depth_dev, const kde_float3* points_dev, const uint8_t* bgr_dev, void* stream)

@@ -227,8 +227,17 @@ int launch_ers_enhance(int width, int height, int n, const float* rd, const uint
 int launch_spdsr_init_normalized(const Camera& c, float* nxy, hipStream_t s);
 int launch_spdsr_cluster_planes(int width, int height, int n, int nclusters, int table_frames, const int32_t* labels,
                                 const kde_float3* pts, double* sums, double* cov, float* nd, int* moments_dirty, hipStream_t s);
+// state of the resident sweep launches of one SPDSR handle (spdsr_kernels.hip: mrf_sweeps_resident_kernel)
+struct SpdsrResident {
+    int* flags = nullptr;       // device: one announcement counter per workgroup, a 128-byte line each
+    int* status = nullptr;      // pinned host: 0, or (workgroup + 1) that gave up waiting
+    int gen = 0;                // the counters run on across calls
+    int cus = 0, cooperative = 0;
+};
+int spdsr_resident_init(SpdsrResident* r);
+void spdsr_resident_release(SpdsrResident* r);
 int launch_spdsr_plane_projection(int width, int height, int n, int nclusters, const float* nd, const int32_t* labels,
                                   const kde_float3* pts, const float* nxy, kde_float3* plane_fitted, kde_float3* opt_a,
-                                  kde_float3* opt_b, int sweeps, kde_float3** result, hipStream_t s);
+                                  kde_float3* opt_b, int sweeps, kde_float3** result, SpdsrResident* res, hipStream_t s);
 
 }  // namespace kde

@@ -448,6 +448,283 @@ __global__ __launch_bounds__(256) void mrf_sweep2_kernel(int width, int height, 
 }
 #endif  // KDE_AB_SWITCHES
 
+#ifdef KDE_AB_SWITCHES
+// ---------------------------------------------------------------------------------------------------------------------
+// All 20 sweeps of ONE frame in one launch, the state resident in LDS (r05).  The 20 launches above spend more than half of
+// their 15 us each on fill, drain and the staging round trip (VALU busy 0.42), and a frame's z plane is small: 1080p is
+// 8.3 MB against 40 MB of LDS on the chip.  So the frame is cut into one block per workgroup (a GX x GY grid of at most one
+// workgroup per CU, 1024 threads each); a workgroup keeps the tap-visible z of its block + a halo of 2 in two LDS planes
+// (ping-pong) and its own pixels' state (|z|, "rewritten" flag, plane-fitted z) in registers for all sweeps.  Per sweep
+// only the 2-pixel rim of the block goes through memory: written to the global z plane of the sweep's parity with sc1
+// (write-through) stores, announced by one agent-scope flag store per workgroup, and read by the (up to 8) neighbours
+// with sc1 loads once their poll of that flag has matched (the hand-off form of MI355X_MICROARCH.md's table, first row:
+// every storing wave drains its stores, workgroup barrier, ONE lane signals; ONE wave polls, workgroup barrier, sc1
+// loads).  Two parities suffice: a workgroup can only write rim k + 2 after every neighbour has announced k + 1, i.e.
+// has finished reading rim k.
+// Per pixel the arithmetic is mrf_sweep_kernel's, instruction for instruction (same pairs: even global column first, same
+// unit order), so the result is bit-identical to the 20 launches (tests/test_gpu_dasp_ers.py).
+// Progress needs every workgroup resident: the launch is cooperative (the runtime checks the grid against the occupancy
+// and runs cooperative launches of a device one after the other), and every spin is bounded -- a workgroup that waits longer
+// than kResidentTimeoutTicks raises `status` (host-visible), which ends every other spin as well; the caller sees
+// KDE_ERR_HIP at its next call instead of a hang.
+//
+// MEASURED AND NOT USED (measurement build only, KDE_SPDSR_RESIDENT=1 cooperative / 2 plain launch; tools/bench_spdsr.py,
+// profiles/r05_ab_spdsr_resident.txt): bit-identical, the kernel takes 284 us per 1080p frame against 20 x 15.2 = 304 us
+// plus 19 boundaries, but SPDepthSuperResolution::Process gains only 0.899 -> 0.873 ms (-2.9 %) with a PLAIN launch -- which
+// is not safe when two handles run on one device (two partially resident grids wait for each other until the spin bound) --
+// and LOSES with the cooperative launch that makes it safe: 0.927 ms (the runtime's cooperative queue costs ~50 us per
+// launch here; 640x480: 0.309 / 0.350 / 0.305 ms).  The sweep is bound by its own arithmetic (25 units x (5 packed + 2
+// v_rcp_f32) per pair: ~11 of the 14 us per sweep), not by the launch structure the resident form removes.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kResThreads = 1024;
+constexpr int kResMaxGrid = 16;                       // blocks per frame side: 16 x 16 = one workgroup per CU
+constexpr unsigned long long kResidentTimeoutTicks = 100000000ull;     // 1 s of the 100 MHz wall clock
+
+struct ResidentArgs {
+    int width, height, sweeps;
+    int gx, gy, bw, bh;                               // grid of blocks, block size in pixels (bw even)
+    float* zplane[2];                                 // global z planes: [0] holds the initial state and receives rims of even parity
+    const float* pfz;
+    int* flags;                                       // one int per workgroup, 32 ints apart (a 128-byte line each)
+    int gen;                                          // flags count up across calls: sweep k of this call is announced as gen + k + 1
+    int* status;                                      // host-visible: 0 = fine, else (workgroup + 1) that gave up
+};
+
+__device__ __forceinline__ void st_sc1(float* p, float v)
+{
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float* p)
+{
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <int MAXP>     // pairs of pixels a thread owns at most
+__global__ __launch_bounds__(kResThreads) void mrf_sweeps_resident_kernel(const ResidentArgs a)
+{
+    constexpr int R = 2, WIN = 5, HALF = 2;
+    extern __shared__ __attribute__((aligned(16))) float res_lds[];
+    __shared__ int published;                         // waves that have drained their rim stores, counted across sweeps
+    const int LP = a.bw + 2 * R, LH = a.bh + 2 * R;   // LDS plane: block + halo, pitch even
+    float* plane[2] = {res_lds, res_lds + LP * LH};
+    const int tid = threadIdx.x;
+    const int bxi = (int)blockIdx.x % a.gx, byi = (int)blockIdx.x / a.gx;
+    const int X0 = bxi * a.bw, Y0 = byi * a.bh;
+    const int bw_real = min(a.bw, a.width - X0), bh_real = min(a.bh, a.height - Y0);     // >= 1 by construction of the grid
+    const int pw = a.bw / 2;                          // pairs per block row
+
+    // ---- initial state: tap-visible z of block + halo from the global plane (written by the previous kernel) ----
+    if (tid == 0) published = 0;
+    for (int i = tid; i < LP * LH; i += kResThreads) {
+        const int ly = i / LP, lx = i - ly * LP;
+        const int gx = X0 + lx - R, gy = Y0 + ly - R;
+        float z = 0.0f;
+        if (gx >= 0 && gx < a.width && gy >= 0 && gy < a.height) z = fabsf(a.zplane[0][(size_t)gy * a.width + gx]);
+        plane[0][i] = z > 50.0f ? z : 0.0f;
+        plane[1][i] = 0.0f;                           // out-of-image halo cells stay 0 in both planes
+    }
+    // ---- this thread's pairs.  Pair list of the block: the RIM first -- the pairs of rows 0, 1, bh - 2, bh - 1 and the first
+    // and last pair of the rows between: what the neighbours read, and the only pairs whose window reaches into the halo --
+    // then the interior.  Slot 0 (pairs 0 .. 1023) holds the whole rim (resident_geometry): it is computed LAST in a sweep,
+    // once the neighbours' rims have arrived, and the interior slots before it need nothing from outside the block.
+    int off[MAXP];                                    // (row * LP + 2 * pair column) = top-left cell of the 5 x 6 window; -1 = no pair
+    s_f2 oz[MAXP], pf[MAXP];
+    unsigned rw = 0, has = 0;                         // bit 2k: pixel 0 of pair k (rewritten / exists), bit 2k + 1: pixel 1
+    const int n_rim = 4 * pw + 2 * (a.bh - 4), n_pairs = pw * a.bh;
+#pragma unroll
+    for (int k = 0; k < MAXP; k++) {
+        const int pi = tid + k * kResThreads;
+        off[k] = -1;
+        oz[k] = pf[k] = s_f2{0.0f, 0.0f};
+        if (pi < n_pairs) {
+            int row, pc;
+            if (pi < 2 * pw) {
+                row = pi / pw; pc = pi - row * pw;
+            } else if (pi < 4 * pw) {
+                const int j = pi - 2 * pw;
+                row = j / pw; pc = j - row * pw; row += a.bh - 2;
+            } else if (pi < n_rim) {
+                const int j = pi - 4 * pw;
+                row = 2 + (j >> 1); pc = (j & 1) ? pw - 1 : 0;
+            } else {
+                const int j = pi - n_rim;                 // interior: rows 2 .. bh - 3, pairs 1 .. pw - 2 (pw > 2 or none is left)
+                row = j / (pw - 2); pc = 1 + j - row * (pw - 2); row += 2;
+            }
+            const int x = X0 + 2 * pc, y = Y0 + row;
+            if (x < a.width && y < a.height) {
+                off[k] = row * LP + 2 * pc;
+                const size_t p = (size_t)y * a.width + x;
+                const bool two = x + 1 < a.width;
+                const float z0 = a.zplane[0][p], z1 = two ? a.zplane[0][p + 1] : 0.0f;
+                oz[k] = s_f2{fabsf(z0), fabsf(z1)};
+                pf[k] = s_f2{a.pfz[p], two ? a.pfz[p + 1] : 0.0f};
+                has |= (1u << (2 * k)) | (two ? (2u << (2 * k)) : 0u);
+                rw |= (z0 < 0.0f ? (1u << (2 * k)) : 0u) | (z1 < 0.0f ? (2u << (2 * k)) : 0u);
+            }
+        }
+    }
+    __syncthreads();
+
+    const unsigned long long t_start = wall_clock64();
+    const float* cur = plane[0];
+    float* nxt = plane[1];
+    // one pair: mrf_sweep_kernel's arithmetic on the planes in LDS
+    auto sweep_pair = [&](int k) {
+        if (off[k] < 0) return;
+        s_f2 z = oz[k];
+        const bool p1 = (has >> (2 * k + 1)) & 1u;
+        const bool c0 = pf[k].x > 50.0f && fabsf(z.x - pf[k].x) < z.x * 0.01f;
+        const bool c1 = p1 && pf[k].y > 50.0f && fabsf(z.y - pf[k].y) < z.y * 0.01f;
+        if (c0 || c1) {
+            s_f2 num = pf[k], den = {1.0f, 1.0f};
+            const s_f2 one = {1.0f, 1.0f}, half = {0.5f, 0.5f};
+#pragma unroll
+            for (int i = 0; i < WIN; i++) {
+                s_f2 q[3], hv[3];
+#pragma unroll
+                for (int m = 0; m < 3; m++) {
+                    q[m] = *reinterpret_cast<const s_f2*>(&cur[off[k] + i * LP + 2 * m]);
+                    hv[m] = s_add_clamp(q[m], q[m]) * half;
+                }
+#pragma unroll
+                for (int u = 0; u < WIN; u++) {
+                    s_f2 oq, h;
+                    if (u <= HALF) {
+                        oq = q[u];
+                        h = hv[u];
+                    } else if (u < WIN - 1) {
+                        oq = __builtin_shufflevector(q[u - HALF], q[u - HALF], 1, 0);
+                        h = __builtin_shufflevector(hv[u - HALF], hv[u - HALF], 1, 0);
+                    } else {
+                        oq = s_f2{q[0].y, q[HALF].x};
+                        h = s_f2{hv[0].y, hv[HALF].x};
+                    }
+                    const s_f2 diff = z - oq;
+                    const s_f2 t1 = one + diff * diff;
+                    const s_f2 filter = s_f2{__builtin_amdgcn_rcpf(t1.x), __builtin_amdgcn_rcpf(t1.y)} * h;
+                    num = __builtin_elementwise_fma(oq, filter, num);
+                    den = den + filter;
+                }
+            }
+            if (c0 && den.x != 0.0f) {
+                z.x = num.x / den.x;
+                rw |= 1u << (2 * k);
+            }
+            if (c1 && den.y != 0.0f) {
+                z.y = num.y / den.y;
+                rw |= 2u << (2 * k);
+            }
+            oz[k] = z;
+        }
+        // what the next sweep's taps see of this pair (a pixel beyond the image edge stays 0)
+        const s_f2 vis = {z.x > 50.0f ? z.x : 0.0f, (p1 && z.y > 50.0f) ? z.y : 0.0f};
+        *reinterpret_cast<s_f2*>(&nxt[off[k] + R * LP + R]) = vis;
+    };
+
+    for (int sw = 0; sw < a.sweeps; sw++) {
+        cur = plane[sw & 1];
+        nxt = plane[(sw + 1) & 1];
+        // ---- A: the interior slots (their windows stay inside the block, complete since the last barrier) ----
+#pragma unroll
+        for (int k = 1; k < MAXP; k++) sweep_pair(k);
+        // ---- H: the neighbours' rims of sweep sw - 1 -> the halo ring of `cur` (the initial load covered sweep 0) ----
+        if (sw > 0) {
+            bool gave_up = false;
+            const int target = a.gen + sw;                        // announcement of rim sw - 1
+            if (tid < 64) {                                       // one wave polls, lane d = direction d
+                bool waiting = false;
+                int nb = 0;
+                if (tid < 8) {
+                    const int d = tid < 4 ? tid : tid + 1;        // 3 x 3 neighbourhood without the centre
+                    const int nx = bxi + d % 3 - 1, ny = byi + d / 3 - 1;
+                    if (nx >= 0 && nx < a.gx && ny >= 0 && ny < a.gy) {
+                        waiting = true;
+                        nb = ny * a.gx + nx;
+                    }
+                }
+                int spins = 0;
+                while (true) {
+                    if (waiting && __hip_atomic_load(&a.flags[nb * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target >= 0) waiting = false;
+                    if (!__any(waiting)) break;
+                    if ((++spins & 63) == 0) {                    // bounded: nobody waits for a workgroup that never became resident
+                        if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 ||
+                            wall_clock64() - t_start > kResidentTimeoutTicks) {
+                            gave_up = true;
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (gave_up && tid == 0) __hip_atomic_store(a.status, (int)blockIdx.x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (__syncthreads_or(gave_up)) return;                // every workgroup leaves: the others see `status` in their own spin
+            const float* __restrict__ g = a.zplane[sw & 1];       // rim sw - 1 went to the plane of parity sw
+            float* ring = plane[sw & 1];
+            const int ring_rows = 2 * R * LP;                     // top R + bottom R rows of the plane, full pitch
+            const int ring_cols = 2 * R * a.bh;                   // left / right R columns of the rows between
+            for (int i = tid; i < ring_rows + ring_cols; i += kResThreads) {
+                int lx, ly;
+                if (i < ring_rows) {
+                    const int r = i / LP;
+                    lx = i - r * LP;
+                    ly = r < R ? r : a.bh + r;                    // plane rows 0, 1, bh + 2, bh + 3
+                } else {
+                    const int j = i - ring_rows, r = j / (2 * R), c = j - r * (2 * R);
+                    ly = R + r;
+                    lx = c < R ? c : a.bw + c;                    // plane columns 0, 1, bw + 2, bw + 3
+                }
+                const int gx = X0 + lx - R, gy = Y0 + ly - R;
+                if (gx >= 0 && gx < a.width && gy >= 0 && gy < a.height) ring[ly * LP + lx] = ld_sc1(&g[(size_t)gy * a.width + gx]);
+            }
+        }
+        __syncthreads();                                          // ring in place (and, for sw == 0, nothing to wait for)
+        // ---- B: slot 0 = the rim (+ the first interior pairs) ----
+        sweep_pair(0);
+        if (sw + 1 == a.sweeps) break;                            // the last sweep's result leaves through the registers below
+        __syncthreads();                                          // `nxt` complete: rim cells for the stores below, all cells for the next A
+        // ---- publish this block's rim of sweep sw to the global plane of parity sw + 1: sc1 stores.  Every wave drains its own
+        // stores and counts itself in LDS; the wave that counts last announces (no workgroup barrier: the others go on) ----
+        {
+            float* __restrict__ g = a.zplane[(sw + 1) & 1];
+            const int rim_rows = 2 * R * bw_real;                         // top R rows + bottom R rows, full width
+            const int rim_cols = 2 * R * max(bh_real - 2 * R, 0);         // left / right R columns of the rows between
+            for (int i = tid; i < rim_rows + rim_cols; i += kResThreads) {
+                int lx, ly;
+                if (i < rim_rows) {
+                    const int r = i / bw_real;
+                    lx = i - r * bw_real;
+                    ly = r < R ? r : bh_real - 2 * R + r;                 // rows 0, 1, bh - 2, bh - 1 (they coincide for bh < 4: harmless)
+                    if (ly < 0) ly = r;
+                } else {
+                    const int j = i - rim_rows, r = j / (2 * R), c = j - r * (2 * R);
+                    ly = R + r;
+                    lx = c < R ? c : bw_real - 2 * R + c;
+                    if (lx < 0) lx = c;
+                }
+                if (lx < bw_real && ly < bh_real)
+                    st_sc1(&g[(size_t)(Y0 + ly) * a.width + X0 + lx], nxt[(ly + R) * LP + lx + R]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((tid & 63) == 0) {
+                const int waves = kResThreads / 64;
+                if (atomicAdd(&published, 1) + 1 == waves * (sw + 1))
+                    __hip_atomic_store(&a.flags[blockIdx.x * 32], a.gen + sw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // ---- final state: signed z (negative = rewritten at least once) for mrf_expand_kernel ----
+    float* __restrict__ zout = a.zplane[a.sweeps & 1];
+#pragma unroll
+    for (int k = 0; k < MAXP; k++) {
+        if (off[k] < 0) continue;
+        const int row = off[k] / LP, col = off[k] - row * LP;
+        const size_t p = (size_t)(Y0 + row) * a.width + X0 + col;
+        zout[p] = ((rw >> (2 * k)) & 1u) ? -oz[k].x : oz[k].x;
+        if ((has >> (2 * k + 1)) & 1u) zout[p + 1] = ((rw >> (2 * k + 1)) & 1u) ? -oz[k].y : oz[k].y;
+    }
+}
+#endif  // KDE_AB_SWITCHES (resident sweeps)
+
 __global__ __launch_bounds__(kThreads) void mrf_expand_kernel(int npix, const float* __restrict__ zfinal,
                                                              const kde_float3* __restrict__ pts,
                                                              const float2* __restrict__ nxy, kde_float3* __restrict__ out)
@@ -509,9 +786,60 @@ int launch_spdsr_cluster_planes(int width, int height, int n, int nclusters, int
     return KDE_OK;
 }
 
+#ifdef KDE_AB_SWITCHES
+// Geometry of the resident form for a frame, or false when it does not apply: one block per workgroup on a grid of at most
+// kResMaxGrid x kResMaxGrid, block width even (pairs start on even global columns, as in mrf_sweep_kernel), blocks at least
+// 4 x 4 (a halo of 2 must not reach past the direct neighbour), both LDS planes within the CU's 160 KB, <= 8 pairs per thread
+static bool resident_geometry(int width, int height, int cus, ResidentArgs& a, size_t& lds, int& maxp)
+{
+    const int g = cus >= kResMaxGrid * kResMaxGrid ? kResMaxGrid : 0;
+    if (!g) return false;
+    a.bw = (ceil_div(width, g) + 1) / 2 * 2;
+    a.bh = ceil_div(height, g);
+    if (a.bw < 4 || a.bh < 4) return false;
+    a.gx = ceil_div(width, a.bw);
+    a.gy = ceil_div(height, a.bh);
+    lds = (size_t)2 * (a.bw + 4) * (a.bh + 4) * sizeof(float);
+    const int pairs = a.bw / 2 * a.bh;
+    maxp = ceil_div(pairs, kResThreads) <= 4 ? 4 : 8;
+    const int rim = 4 * (a.bw / 2) + 2 * (a.bh - 4);                // the rim pairs are one thread's slot 0 each
+    return lds <= 150 * 1024 && ceil_div(pairs, kResThreads) <= 8 && rim <= kResThreads;
+}
+#endif
+
+int spdsr_resident_init(SpdsrResident* r)
+{
+#ifdef KDE_AB_SWITCHES       // the resident sweep launch exists in the measurement build only (see mrf_sweeps_resident_kernel)
+    int dev = 0;
+    KDE_HIP_TRY(hipGetDevice(&dev));
+    KDE_HIP_TRY(hipDeviceGetAttribute(&r->cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int coop = 0;
+    KDE_HIP_TRY(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev));
+    r->cooperative = coop;
+    KDE_HIP_TRY(hipMalloc(&r->flags, (size_t)kResMaxGrid * kResMaxGrid * 32 * sizeof(int)));
+    KDE_HIP_TRY(hipMemset(r->flags, 0, (size_t)kResMaxGrid * kResMaxGrid * 32 * sizeof(int)));
+    KDE_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r->status), sizeof(int), hipHostMallocDefault));
+    *r->status = 0;
+    r->gen = 0;
+    KDE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mrf_sweeps_resident_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    KDE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mrf_sweeps_resident_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+#else
+    (void)r;
+#endif
+    return KDE_OK;
+}
+
+void spdsr_resident_release(SpdsrResident* r)
+{
+    if (r->flags) (void)hipFree(r->flags);
+    if (r->status) (void)hipHostFree(r->status);
+    r->flags = nullptr;
+    r->status = nullptr;
+}
+
 int launch_spdsr_plane_projection(int width, int height, int n, int nclusters, const float* nd, const int32_t* labels,
                                   const kde_float3* pts, const float* nxy, kde_float3* plane_fitted, kde_float3* opt_a,
-                                  kde_float3* opt_b, int sweeps, kde_float3** result, hipStream_t s)
+                                  kde_float3* opt_b, int sweeps, kde_float3** result, SpdsrResident* res, hipStream_t s)
 {
     const int npix = width * height;
     // opt_b (12 B/px per frame) is carved into the three compact planes of the sweeps: z ping, z pong, plane-fitted z
@@ -522,6 +850,35 @@ int launch_spdsr_plane_projection(int width, int height, int n, int nclusters, c
     hipLaunchKernelGGL(set_pseudo_depth_kernel, dim3(ceil_div(npix, kThreads), n), dim3(kThreads), 0, s, npix, nclusters,
                        reinterpret_cast<const float4*>(nd), labels, pts, reinterpret_cast<const float2*>(nxy), plane_fitted,
                        zping, pfz);
+#ifdef KDE_AB_SWITCHES
+    // ---- one frame: all sweeps in one launch, state resident in LDS (mrf_sweeps_resident_kernel; measured, not used) ----
+    static const int resident_mode = [] { const char* e = KDE_AB_ENV("KDE_SPDSR_RESIDENT"); return e ? e[0] - '0' : 0; }();   // 1 cooperative, 2 plain
+    ResidentArgs ra;
+    size_t lds = 0;
+    int maxp = 4;
+    if (resident_mode && n == 1 && sweeps >= 2 && res && res->flags && (res->cooperative || resident_mode == 2) &&
+        resident_geometry(width, height, res->cus, ra, lds, maxp)) {
+        if (*res->status != 0)
+            return fail(KDE_ERR_HIP, "SPDSR: a resident sweep launch gave up waiting for workgroup %d (device shared with another "
+                                     "persistent kernel?)", *res->status - 1);
+        ra.width = width; ra.height = height; ra.sweeps = sweeps;
+        ra.zplane[0] = zping; ra.zplane[1] = zpong; ra.pfz = pfz;
+        ra.flags = res->flags; ra.gen = res->gen; ra.status = res->status;
+        res->gen += sweeps + 1;
+        void* args[] = {&ra};
+        const void* fn = maxp == 4 ? reinterpret_cast<const void*>(&mrf_sweeps_resident_kernel<4>)
+                                   : reinterpret_cast<const void*>(&mrf_sweeps_resident_kernel<8>);
+        if (resident_mode == 2) KDE_HIP_TRY(hipLaunchKernel(fn, dim3(ra.gx * ra.gy), dim3(kResThreads), args, lds, s));
+        else KDE_HIP_TRY(hipLaunchCooperativeKernel(fn, dim3(ra.gx * ra.gy), dim3(kResThreads), args, (unsigned)lds, s));
+        hipLaunchKernelGGL(mrf_expand_kernel, dim3(ceil_div(npix, kThreads), n), dim3(kThreads), 0, s, npix, ra.zplane[sweeps & 1], pts,
+                           reinterpret_cast<const float2*>(nxy), opt_a);
+        KDE_HIP_TRY(hipGetLastError());
+        *result = opt_a;
+        return KDE_OK;
+    }
+#else
+    (void)res;
+#endif
     float *in = zping, *out = zpong;
     dim3 grid((unsigned)(ceil_div(width, kSwBX * 2) * ceil_div(height, kSwBY) * n));
     static const int band = KDE_AB_ENV("KDE_SWEEP_NO_BAND_WALK") == nullptr ? 1 : 0;      // (measurement build only)

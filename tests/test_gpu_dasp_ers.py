@@ -665,3 +665,74 @@ def test_spdsr_two_sweeps_per_launch_equal_single_sweeps_bitwise(torch_cuda, tmp
         res.append(np.load(path))
     assert res[0].shape == res[1].shape and np.isfinite(res[0]).mean() > 0.9
     assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
+
+
+_RESIDENT_CHILD = (
+    "import os, sys, threading, numpy as np, torch; sys.path.insert(0, %r)\n"
+    "sys.path.insert(0, os.path.join(sys.path[0], 'tools', 'hooks')); import ab; ab.use_ab_library()\n"
+    "from kinectdepthmapenhancement_amd import filters as F, synth\n"
+    "from oracle import oracle as O\n"
+    "def run(seed, w, h, g, reps, stream=None):\n"
+    "    with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):\n"
+    "        bgr, depth = synth.make_frame(seed, w, h); K = synth.intrinsics(w, h)\n"
+    "        pts = O.p2r_depth(depth, K).view(np.float32).reshape(h, w, 3)\n"
+    "        sr = F.SPDepthSuperResolution(w, h); sr.SetParametor(g[0], g[1], K)\n"
+    "        a = (torch.from_numpy(depth).cuda(), torch.from_numpy(np.ascontiguousarray(pts)).cuda(), torch.from_numpy(bgr).cuda())\n"
+    "        for _ in range(reps): sr.Process(*a)\n"
+    "        return np.asarray(sr.getOptimizedPoints_Host()).copy().ravel()\n"
+    "cases, threads = %r, int(sys.argv[2])\n"
+    "outs = [None] * len(cases)\n"
+    "if threads:\n"
+    "    run(*cases[0], 1)\n"
+    "    th = [threading.Thread(target=lambda i=i: outs.__setitem__(i, run(*cases[i], 25, torch.cuda.Stream()))) for i in range(len(cases))]\n"
+    "    [t.start() for t in th]; [t.join(120) for t in th]\n"
+    "    assert not any(t.is_alive() for t in th)\n"
+    "else:\n"
+    "    outs = [run(*c, 4) for c in cases]\n"
+    "np.save(sys.argv[1], np.concatenate(outs))\n")
+
+
+def _resident_child(tmp_path, cases, mode, threads=0):
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    path = str(tmp_path / f"opt_resident_{mode}_{threads}.npy")
+    r = subprocess.run([sys.executable, "-c", _RESIDENT_CHILD % (ROOT, cases), path, str(threads)], env=dict(os.environ, KDE_SPDSR_RESIDENT=str(mode)),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(path)
+
+
+def test_spdsr_resident_sweeps_equal_the_20_launches_bitwise(torch_cuda, F, oracle, synth, tmp_path):
+    """The measured-and-rejected LDS-resident form of Projection_GPU's 20 mrf_optimization sweeps (mrf_sweeps_resident_kernel:
+    one launch, one block of the frame per CU, only the 2-pixel rims go through memory between sweeps; measurement build only,
+    KDE_SPDSR_RESIDENT = 1 cooperative / 2 plain launch).  Per pixel the arithmetic is mrf_sweep_kernel's, so the optimised
+    cloud must equal the PRODUCT library's 20 launches bit for bit, call after call (the announcement counters run on).
+    Sizes: 1080p (blocks of 120 x 68), 640x480, and a ragged frame with an odd width and partial last blocks."""
+    cases = ((33, 1920, 1080, (15, 20)), (33, 640, 480, (15, 20)), (33, 203, 131, (5, 7)))
+    want = []
+    for seed, w, h, g in cases:
+        bgr, depth = synth.make_frame(seed, w, h)
+        K = synth.intrinsics(w, h)
+        pts = oracle.p2r_depth(depth, K).view(np.float32).reshape(h, w, 3)
+        sr = F.SPDepthSuperResolution(w, h)
+        sr.SetParametor(g[0], g[1], K)
+        sr.Process(dev(torch_cuda, depth), dev(torch_cuda, np.ascontiguousarray(pts)), dev(torch_cuda, bgr))
+        want.append(host(sr.getOptimizedPoints_Device()).ravel())
+    want = np.concatenate(want)
+    assert np.isfinite(want).mean() > 0.9
+    for mode in (1, 2):
+        got = _resident_child(tmp_path, cases, mode)
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"resident mode {mode}"
+
+
+def test_spdsr_resident_cooperative_launches_from_three_host_threads(torch_cuda, F, oracle, synth, tmp_path):
+    """three host threads, each with its own stream and SPDSR handle, call Process 25 times concurrently on the measurement build
+    with the COOPERATIVE resident launch: the runtime runs cooperative launches of a device one after the other, so every
+    workgroup of a launch is resident and no launch waits for another's (a spin that gave up would fail the child); results
+    equal the product library's bit for bit"""
+    cases = ((41, 640, 480, (15, 20)), (42, 640, 480, (15, 20)), (43, 640, 480, (15, 20)))
+    want = _resident_child(tmp_path, cases, 0)
+    got = _resident_child(tmp_path, cases, 1, threads=1)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

@@ -4,7 +4,8 @@ tests of those kernels bind to it with use_ab_library() BEFORE the first library
 import os
 
 AB_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkde_hip_ab.so")
-SWITCHES = ("KDE_K0_2X2", "KDE_K0_BAND_WALK", "KDE_K8_NO_BAND_WALK", "KDE_K10_MASK_PRODUCT", "KDE_SWEEP_NO_BAND_WALK", "KDE_SPDSR_TWO_SWEEPS")
+SWITCHES = ("KDE_K0_2X2", "KDE_K0_BAND_WALK", "KDE_K8_NO_BAND_WALK", "KDE_K10_MASK_PRODUCT", "KDE_SWEEP_NO_BAND_WALK", "KDE_SPDSR_TWO_SWEEPS",
+            "KDE_SPDSR_RESIDENT")
 
 
 def use_ab_library() -> str:
