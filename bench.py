@@ -184,9 +184,9 @@ def pmc_lookup(path, window, variant_name=None):
         m = re.match(r"w(\d+)-(pk|sc)(\d+)-(\d+)x(\d+)-(true|false)(-v[14])?(-noelide)?$", variant_name or "")
         if m:
             w, kind, npx, bx, by, cache, vl, noel = m.groups()
-            if kind == "pk":     # jbf_pk_kernel<WIN, NP, BX, BY, CACHE, CSKIP, VL, ELIDE_ON>
+            if kind == "pk":     # jbf_pk_kernel<WIN, NP, BX, BY, CACHE, CSKIP, VL, ELIDE_ON, CR> (CR = 0 or WIN in the product build)
                 pat = (rf"jbf_pk_kernel<{w}, {npx}, {bx}, {by}, {cache}, (true|false), {'true' if vl == '-v4' else 'false'}, "
-                       rf"{'false' if noel else 'true'}>")
+                       rf"{'false' if noel else 'true'}(, \d+)?>")
             else:                # jbf_fast_kernel<WIN, PX, BX, BY, CACHE, CSKIP>
                 pat = rf"jbf_fast_kernel<{w}, {npx}, {bx}, {by}, {cache}, (true|false)>"
         c = [k for k in pj["kernels"] if re.search(pat, k["kernel"])]

@@ -38,7 +38,7 @@ def test_cost_table_has_three_issue_classes(vm):
 
 def test_k1_mix_reproduces_the_committed_fraction(vm):
     pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_bench.json")))
-    k = next(k for k in pj["kernels"] if k["kernel"].startswith("jbf_pk_kernel<11, 2, 16, 16, false, true, true, true>"))
+    k = next(k for k in pj["kernels"] if k["kernel"].startswith("jbf_pk_kernel<11, 2, 16, 16, false, true, true, true"))
     c, d = k["counters"], k["derived"]
     assert 0.85 < d["valu_cycles_frac"] <= 1.0 and d["valu_cycles_floor_frac"] < d["valu_cycles_frac"] <= d["valu_cycles_frac_at_measured_costs"]
     import pmc_report
