@@ -71,7 +71,8 @@ def pytest_terminal_summary(terminalreporter):
             terminalreporter.write_line(line)
 
 
-CENSUS_LOG = {}     # what -> deviation census (oracle.deviation_census); tools/census_report.py reads the same function
+CENSUS_LOG = {}     # what -> deviation census of the last comparison of that name (oracle.deviation_census)
+CENSUS_ALL = []     # every census taken in this process (tools/stress_parity.py totals them)
 
 
 def assert_depth_close(got, ref, rtol=1e-4, ill=None, max_bad=0, what="depth", max_flagged=None, max_far=None, max_zero_diff=None,
@@ -95,6 +96,7 @@ def assert_depth_close(got, ref, rtol=1e-4, ill=None, max_bad=0, what="depth", m
     r = parity_check(got, ref, ill, rtol, grid=grid)
     c = r["census"]
     CENSUS_LOG[what] = c
+    CENSUS_ALL.append(c)
     if ill is not None or max_far is not None or max_zero_diff is not None:
         PARITY_LOG.append(f"{what} [census vs float32]: > {rtol:g} away {c['n_rel_gt_rtol']} ({c['frac_rel_gt_rtol']:.2e}; unflagged "
                           f"{c['n_rel_gt_rtol_unflagged']}), zero mask differs {c['n_zero_mask_differs']} ({c['frac_zero_mask_differs']:.2e}: "

@@ -337,6 +337,16 @@ def run(cases=100, seed=1, dump="", ers=False, only=""):
                   f"max {max(bf):.2e} (of it, taps ON a decision -- the non-GRID part: median {np.median(df):.2e} p99 {np.percentile(df, 99):.2e} "
                   f"max {max(df):.2e}; bound asserted for frames >= 64x48: {DECISION_MAX}); strict-pixel max rel err median {np.median(mr):.2e} max {max(mr):.2e}; average within "
                   f"{max(af):.2f} of its float32 bound at worst")
+    from conftest import CENSUS_ALL
+    if CENSUS_ALL:
+        px = sum(c["n"] for c in CENSUS_ALL)
+        far = sum(c["n_rel_gt_rtol"] for c in CENSUS_ALL)
+        print(f"stress: [census vs float32, END TO END] {len(CENSUS_ALL)} depth comparisons, {px} pixels: more than 1e-4 from the float32 value "
+              f"{far} ({far / max(1, px):.2e}; unflagged among them {sum(c['n_rel_gt_rtol_unflagged'] for c in CENSUS_ALL)}), zero mask differs "
+              f"{sum(c['n_zero_mask_differs'] for c in CENSUS_ALL)} (gained {sum(c['n_gained_zero'] for c in CENSUS_ALL)}, lost "
+              f"{sum(c['n_lost_zero'] for c in CENSUS_ALL)}; outside the flagged class {sum(c['n_zero_mask_differs_unflagged'] for c in CENSUS_ALL)}), "
+              f"NaN mask differs {sum(c['n_nan_mask_differs'] for c in CENSUS_ALL)}; worst comparison: "
+              f"{max(c['frac_rel_gt_rtol'] for c in CENSUS_ALL):.2e} of its pixels beyond 1e-4")
     print(f"stress: {a.cases} cases, {bad} violations")
     return bad
 
