@@ -25,7 +25,7 @@ cpif $S/mrf_fhd.json $D/${R}_mrf_fhd.json
 cpif $S/mrf_vga.json $D/${R}_mrf_vga.json
 cpif $S/feeders.json $D/${R}_feeders_128xfhd.json
 cpif $S/shard_vs_bench.json $D/${R}_shard_replay_vs_bench_1gpu.json
-cpif $S/sweep_k1_variants.log $D/${R}_sweep_k1_variants.log
+cpif $S/sweep_k1_variants.log $D/${R}_sweep_k1_tiles.log
 cpif $S/micro_pmc_a.txt $D/${R}_valu_microbench.txt
 # (profiles/valu_costs.json needs the micro_pmc step -- cycles per opcode -- and is only copied from a round that ran it)
 [ -d $S/micro_pmc ] && cpif $S/valu_costs.json $D/valu_costs.json
