@@ -457,9 +457,8 @@ def main():
     # process groups: gloo for the rendezvous, RCCL on top of it if it comes up on every rank; else the in-process
     # fallback of SURVEY 8(e) -- nothing is re-executed, the run is flagged [REPLICAS ONLY] (sharding.ShardComm)
     verdict = json.loads(os.environ["KDE_RCCL_PROBE_VERDICT"]) if os.environ.get("KDE_RCCL_PROBE_VERDICT") else None
-    if args.share_device and args.backend == "nccl" and world > 1 and not args.force_rccl_failure and not (verdict and not verdict["ok"]):
-        # (with a failed probe verdict the ranks never touch RCCL: that combination is the hardware test of the probes)
-        raise SystemExit("--share-device needs --backend gloo (RCCL wants one device per rank)")
+    # (--share-device with --backend nccl: RCCL wants one device per rank, so the probes / the bring-up fail and the run goes on
+    #  over gloo, flagged -- the closest a one-GPU box gets to a broken node; tests/test_gpu_sharding.py uses exactly that)
     comm = sharding.ShardComm(args.backend, local_rank, use_gpu=not args.dry_run, force_rccl_failure=args.force_rccl_failure,
                               rccl_timeout_s=args.rccl_timeout, probe=False if args.no_rccl_probe else verdict)
     barrier = comm.barrier

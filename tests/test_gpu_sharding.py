@@ -183,3 +183,19 @@ def test_cpp_host_bounds_ncclCommInitAll(torch_cuda):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert "not finished after 3 s, abandoned" in line["params_broadcast"] and line["verified"] is True
     assert time.time() - t0 < 120
+
+
+def test_under_a_launcher_every_rank_probes_real_rccl_for_itself(torch_cuda):
+    """the driver's N > 1 command form (torch.distributed.run starts the ranks, no parent of ours) with a REAL RCCL failure: two
+    ranks on the box's one GPU.  Every rank starts the probe of its own rank before its first HIP call; the probes fail (or are
+    killed at the deadline), the verdicts are exchanged over gloo, and the same two processes filter their shards over gloo"""
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "nccl",
+                        "--rccl-timeout", "45", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-extra", "--no-verify", "--wakeup-ms", "0",
+                        "--frames-per-gpu", "8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert time.time() - t0 < 300
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["rccl"]["probe"]["ok"] is False and j["rccl"]["probe"]["by"] == "every rank, for itself" and j["rccl"]["bring_up_s"] is None
+    assert j["replicas_only"] is True and "[REPLICAS ONLY]" in j["config"]["sharding"] and j["ranks_seen"] == 2 and j["value"] > 0
