@@ -172,6 +172,17 @@ int main()
         dasp.getRandomColorImage();
         dasp.releaseVideo();
         expect(avg.rows == H && dl.cols == W, "DepthAdaptiveSuperpixel viewers render");
+        // as<M>(): a view for any cv::Mat_<cv::Vec3b>-like type (rows, cols, pixel pointer, step)
+        struct Vec3bLike { uint8_t val[3]; };
+        struct MatLike {
+            typedef Vec3bLike value_type;
+            int rows, cols;
+            value_type* data;
+            size_t step;
+            MatLike(int r, int c, value_type* d, size_t s) : rows(r), cols(c), data(d), step(s) {}
+        };
+        MatLike view = rnd.as<MatLike>();
+        expect(view.rows == H && view.cols == W && view.step == (size_t)W * 3 && (uint8_t*)view.data == rnd.data(), "HostImage8UC3::as<MatLike>() is a view");
     }
 
     // ---- ProcessBatch == per-frame Process, to the bit ----
