@@ -221,17 +221,24 @@ __global__ __launch_bounds__(kPreBX* kPreBY, (R <= 2 ? KDE_K0_RP_WAVES : 0)) voi
     // batches), and concurrently running workgroups of an XCD only share the one halo line between two runs.
     // -> this workgroup's it-th tile, or -1 when it has none left (all scalars)
     constexpr int kRun = 4;
+    // the band of this workgroup's XCD, the workgroups that share it, and how many FULL runs each of them gets: what is left
+    // after those (fewer than kRun x workgroups tiles) is dealt tile by tile, so that no workgroup ends up a whole run
+    // behind the others (64 x 640x480: 1200 runs over 224 workgroups per XCD would be 6 runs for some and 5 for the rest --
+    // 24 against 21.4 tiles on average; with the remainder dealt singly it is 22)
+    const unsigned w_xcd = blockIdx.x % 8u, w_slot = blockIdx.x / 8u;
+    const unsigned w_per = (unsigned)total / 8u, w_rem = (unsigned)total % 8u;
+    const unsigned w_start = w_xcd * w_per + (w_xcd < w_rem ? w_xcd : w_rem), w_len = w_per + (w_xcd < w_rem ? 1u : 0u);
+    const unsigned w_wgs = (gridDim.x + 7u - w_xcd) / 8u;                 // workgroups that run on this XCD
+    const unsigned w_full = a.band_walk == 2 ? w_len / ((unsigned)kRun * w_wgs) : 0u;
     auto tile_index = [&](int it) -> int {
         if (a.band_walk != 2) {
             const long long L = (long long)blockIdx.x + (long long)it * gridDim.x;
             return L < total ? tile_of((int)L) : -1;
         }
-        const unsigned xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u;
-        const unsigned per = (unsigned)total / 8u, rem = (unsigned)total % 8u;
-        const unsigned start = xcd * per + (xcd < rem ? xcd : rem), len = per + (xcd < rem ? 1u : 0u);
-        const unsigned wgs = (gridDim.x + 7u - xcd) / 8u;                 // workgroups that run on this XCD
-        const unsigned pos = (unsigned)kRun * (slot + ((unsigned)it / kRun) * wgs) + (unsigned)it % kRun;
-        return pos < len ? (int)(start + pos) : -1;
+        unsigned pos;
+        if ((unsigned)it < w_full * kRun) pos = (unsigned)kRun * (w_slot + ((unsigned)it / kRun) * w_wgs) + (unsigned)it % kRun;
+        else pos = w_full * kRun * w_wgs + w_slot + ((unsigned)it - w_full * kRun) * w_wgs;
+        return pos < w_len ? (int)(w_start + pos) : -1;
     };
     // (frame, tile row, tile column) of linear tile index L: computed ONCE per tile (when it is prefetched) and carried to
     // the iteration that computes it; the two divisions are multiplications (fastdiv24, exact for < 2^24 tiles)
