@@ -707,8 +707,14 @@ __device__ __forceinline__ uint32_t add_byte3(uint32_t w, uint32_t acc)
 
 // FUSED_LABEL = false keeps r03's form of the pass-1 label test (weight times a {0,1} mask: one packed instruction more per
 // unit) for the A/B of tools/bench_chain.py (KDE_K10_MASK_PRODUCT=1); the outputs are bit-identical
+// KDE_K10_WAVES = waves per SIMD the register allocator must leave room for (0 = no bound: 80 VGPRs, 6 workgroups per CU).
+// A single 1080p frame is 4050 workgroups: on 6 x 256 slots that is 2.64 rounds (the third 64 % full), on 8 x 256 it is
+// 1.98 -- tools/ab_k10_waves.sh measures whether the 6 spilled registers of the 64-VGPR build cost less than the tail.
+#ifndef KDE_K10_WAVES
+#define KDE_K10_WAVES 0
+#endif
 template <bool FUSED_LABEL>
-__global__ __launch_bounds__(kE7BX* kE7BY) void enhance7_pk_kernel(const Enh7PkDev a)
+__global__ __launch_bounds__(kE7BX* kE7BY) __attribute__((amdgpu_waves_per_eu(KDE_K10_WAVES ? KDE_K10_WAVES : 1))) void enhance7_pk_kernel(const Enh7PkDev a)
 {
     constexpr int WIN = 7, R = 3, HALF = 3, SEGP = 4;
     constexpr int NT = kE7BX * kE7BY;

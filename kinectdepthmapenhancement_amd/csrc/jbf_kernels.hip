@@ -792,10 +792,10 @@ long long presmooth_resident_blocks(int radius)
 //      different L2s: K0 read 3.04 x its algorithmic bytes on 64 x 640x480 (total traffic 2.03 x);
 //   1  XCD bands: horizontally adjacent tiles meet in one L2 (reads 0.99 x, total 1.02 x) but are staged by DIFFERENT
 //      workgroups at the same time; best while a launch's input fits the eight L2s (one 1080p frame 18.1 vs 19.1 us);
-//   2  XCD bands in runs of four adjacent tiles (384 bytes = three lines) per workgroup: the shared lines are re-read by the
-//      same workgroup a moment later (reads 1.00 x, total 1.05 x); on batches it is as fast as the linear walk inside the
-//      headline step (0.0855 vs 0.0846 ms on 64 x 640x480, within the run-to-run spread) and faster alone / on 1080p batches
-//      (8 x 1080p: 0.0701 vs 0.0721 ms in the step, 0.0649 vs 0.0681 alone) -- at half the HBM traffic.
+//   2  XCD bands in runs of four adjacent tiles (384 bytes = three lines) per workgroup, the remainder after the full runs
+//      dealt tile by tile: the shared lines are re-read by the same workgroup a moment later (reads 1.00 x, total 1.04 x); on
+//      batches it is as fast as the other two inside the headline step (0.0850 vs 0.0837 linear / 0.0843 bands on 64 x 640x480,
+//      within the run-to-run spread; 8 x 1080p: 0.0703 vs 0.0708 / 0.0707) -- at half the HBM traffic of the linear walk.
 static int k0_band_walk(int width, int height, int n)
 {
     return (long long)width * height * n * 3 <= (32ll << 20) ? 1 : 2;
