@@ -254,3 +254,25 @@ def test_envelope_cross_check_admits_zero_where_binary64_finds_no_weight(oracle)
     assert oracle.parity_check(other, ref, env)["bad"][y, x]
     st_zero = oracle.stage_check(z["got"], st)
     assert not st_zero["bad"][y, x]
+
+
+def test_deviation_census_counts_every_class(oracle):
+    """oracle.deviation_census (round 5): the END-TO-END distance from the float32 value, counted over all pixels whatever
+    their class -- pixels beyond rtol, zero-mask differences in both directions, NaN-mask differences, and the same over a
+    GRID map; parity_check carries it as `census`"""
+    ref = np.array([[0.0, 1000.0, 2000.0, 3000.0, np.nan, 0.0, 500.0, 700.0]], np.float32)
+    got = np.array([[5.0, 1000.05, 0.0, 3000.0, np.nan, 0.0, np.nan, 700.5]], np.float32)
+    flagged = np.array([[0, 1, 1, 0, 0, 0, 0, 0]], bool)
+    grid = np.array([[1, 0, 0, 0, 0, 0, 0, 1]], bool)
+    c = oracle.deviation_census(got, ref, flagged=flagged, grid=grid, rtol=1e-4)
+    assert c["n"] == 8
+    # beyond rtol where both hold a number: 1000.05 vs 1000 (5e-5: inside), 700.5 vs 700 (7e-4: beyond, unflagged, GRID)
+    assert (c["n_rel_gt_rtol"], c["n_rel_gt_rtol_flagged"], c["n_rel_gt_rtol_unflagged"]) == (1, 0, 1)
+    assert (c["n_zero_mask_differs"], c["n_gained_zero"], c["n_lost_zero"]) == (2, 1, 1)      # 2000 -> 0 (flagged), 0 -> 5
+    assert (c["n_zero_mask_differs_flagged"], c["n_zero_mask_differs_unflagged"]) == (1, 1)
+    assert c["n_nan_mask_differs"] == 1 and abs(c["max_rel"] - 0.5 / 700) < 1e-6
+    assert (c["grid_pixels"], c["grid_rel_gt_rtol"], c["grid_zero_mask_differs"]) == (2, 1, 1)
+    same = oracle.deviation_census(ref, ref)
+    assert same["n_rel_gt_rtol"] == 0 and same["n_zero_mask_differs"] == 0 and same["n_nan_mask_differs"] == 0 and same["max_rel"] == 0.0
+    r = oracle.parity_check(got, ref, None, 1e-4, grid=grid)
+    assert r["census"]["n_rel_gt_rtol"] == 1 and r["census"]["grid_pixels"] == 2
