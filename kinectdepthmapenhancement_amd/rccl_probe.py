@@ -63,19 +63,25 @@ def main() -> int:
     import torch
     import torch.distributed as dist
     t0 = time.time()
-    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=DEFAULT_DEADLINE_S))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    g = dist.new_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=DEFAULT_DEADLINE_S))
-    t = torch.ones(1, dtype=torch.float64, device=dev)
-    dist.all_reduce(t, group=g)         # the first collective builds the communicator over xGMI
-    torch.cuda.synchronize(dev)
-    if int(t.item()) != world:
-        print(f"rccl_probe: rank {rank}: all-reduce of 1 over {world} ranks returned {t.item()}", file=sys.stderr)
-        return 4
+    try:
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=DEFAULT_DEADLINE_S))
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+        g = dist.new_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=DEFAULT_DEADLINE_S))
+        t = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, group=g)         # the first collective builds the communicator over xGMI
+        torch.cuda.synchronize(dev)
+        if int(t.item()) != world:
+            raise RuntimeError(f"all-reduce of 1 over {world} ranks returned {t.item()}")
+    except Exception as e:                  # noqa: BLE001 -- the LAST line of the log is what the launcher quotes
+        msg = " ".join(str(e).split())
+        k = msg.find("Duplicate GPU")       # RCCL's own reason, when it gives one, instead of the wrapper text around it
+        print(f"rccl_probe: rank {rank} FAILED: {type(e).__name__}: {(msg[k:] if k >= 0 else msg)[:300]}", file=sys.stderr)
+        sys.stderr.flush()
+        os._exit(4)                         # no communicator teardown: the process is disposable
     print(f"rccl_probe: rank {rank}/{world} ok in {time.time() - t0:.1f} s", file=sys.stderr)
     sys.stderr.flush()
-    os._exit(0)                         # no communicator teardown: the process is disposable
+    os._exit(0)
 
 
 def probe_env(rank: int, world: int, local_rank: int, port: int) -> Dict[str, str]:
@@ -126,7 +132,8 @@ def wait_probes(procs: Sequence[subprocess.Popen], ranks: Sequence[int], deadlin
         q.kde_log.seek(0)
         sys.stderr.write(q.kde_log.read().decode(errors="replace"))
         q.kde_log.close()
-    return {"ok": not bad, "reason": "; ".join(bad) if bad else None, "seconds": round(time.time() - t0, 2)}
+    bad.sort(key=lambda b: "another rank" in b)         # the ranks that failed by themselves first
+    return {"ok": not bad, "reason": "; ".join(bad)[:600] if bad else None, "seconds": round(time.time() - t0, 2)}
 
 
 def run_probes(world: int, deadline_s: float = DEFAULT_DEADLINE_S, share_device: bool = False) -> Dict:
