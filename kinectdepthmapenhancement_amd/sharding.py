@@ -243,6 +243,7 @@ class ShardComm:
                         time.sleep(0.05)
                     raise RuntimeError("gave up: another rank reported a failed bring-up")
                 dev = torch.device("cuda", self.local_rank)
+                torch.cuda.set_device(dev)             # the current device is per THREAD: without this the helper thread sits on cuda:0
                 g = dist.new_group(backend="nccl", device_id=dev, timeout=long_timeout)
                 t = torch.ones(1, dtype=torch.float64, device=dev)
                 dist.all_reduce(t, group=g)             # the first collective builds the communicator over xGMI
