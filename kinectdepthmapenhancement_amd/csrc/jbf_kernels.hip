@@ -839,6 +839,7 @@ int launch_presmooth(const PresmoothLaunch& a, hipStream_t s)
     d.div_tx = make_fastdiv24((uint32_t)d.tiles_x, (uint64_t)d.tiles_x * d.tiles_y);
     const long long cap = a.grid_cap > 0 ? a.grid_cap : 256;
     const unsigned grid = (unsigned)(total < cap ? total : cap);
+    if (d.band_walk == 2 && grid < 8) d.band_walk = 1;       // the run walk gives every XCD's band to the workgroups ON that XCD: it needs all eight
     if (old_form) {
         switch (a.radius) {
             case 1: hipLaunchKernelGGL((presmooth_kernel<1, kPX>), dim3(grid), dim3(kPreBX * kPreBY), 0, s, d); break;

@@ -43,9 +43,10 @@ def test_presmooth_k0_is_bit_exact(torch_cuda, F, oracle, frame, color_fixture):
 
 
 def test_presmooth_tile_walks_agree(torch_cuda, F, oracle, frame):
-    """K0 walks its tiles in XCD bands while a launch's input fits the L2s (<= 32 MiB) and linearly beyond: a batch of 40
-    640x480 frames (36.9 MB, linear walk) must give, frame by frame, the bytes of the single-frame launches (band walk), and
-    frames 0 and 39 the oracle's; a ragged size puts partial tiles into both walks"""
+    """K0 walks its tiles in XCD bands while a launch's input fits the L2s (<= 32 MiB) and in XCD bands of RUNS of four adjacent
+    tiles per workgroup beyond (r05): a batch of 40 640x480 frames (36.9 MB, run walk) must give, frame by frame, the bytes of
+    the single-frame launches (band walk), and frames 0 and 39 the oracle's; a ragged size puts partial tiles, a tile count
+    that is no multiple of four and a remainder after the full runs into both walks"""
     for (w, h, n) in ((640, 480, 40), (637, 479, 40)):
         base = np.stack([frame(20 + i, w, h)[0] for i in range(4)])
         bgr = np.concatenate([np.roll(base, i, axis=2) for i in range(n // 4)])      # 40 distinct frames
