@@ -575,6 +575,16 @@ def main():
         if (W, H, p.window_size) == (640, 480, 11):
             roof["frac_vga_w11"] = roof["frac"]
         roof["k0_avg_launch_ms"] = float(np.mean(k0_ms))
+        try:        # K0 of the same profiled build: HBM traffic over its 6 B/pixel and its share of the VALU roof (profiles/pmc_bench.json)
+            pj = json.load(open(args.pmc_json))
+            k0e = max((k for k in pj["kernels"] if "presmooth_kernel" in k["kernel"]), key=lambda k: k["grid"]) if entry else None
+            if k0e:
+                roof["k0"] = {"kernel": k0e["kernel"], "avg_launch_ms": roof["k0_avg_launch_ms"], "algorithmic_bytes_per_pixel": 6.0,
+                              "traffic_over_algorithmic": k0e["derived"].get("traffic_ratio"), "valu_ceiling_frac": k0e["derived"].get("valu_cycles_frac"),
+                              "lds_conflict_frac": k0e["derived"].get("lds_conflict_frac"),
+                              "tile_walk": "XCD bands in runs of four adjacent tiles per workgroup (inputs > 32 MiB)"}
+        except Exception:       # noqa: BLE001 -- no profile: the live time stands alone
+            pass
         roof["launch_ms_first_min_max"] = [float(k1_ms[0]), float(np.min(k1_ms)), float(np.max(k1_ms))]   # clock ramp shows here
         roof["launch_ms"] = {"mean": k1_avg_ms, "median": float(np.median(k1_ms)), "min": float(np.min(k1_ms)),
                              "max": float(np.max(k1_ms)), "first": float(k1_ms[0])}
