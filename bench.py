@@ -125,7 +125,10 @@ def launch_ranks(args):
     verdict = None
     if (args.backend == "nccl" and not args.no_rccl_probe and not args.force_rccl_failure
             and (not args.dry_run or os.environ.get("KDE_RCCL_PROBE_TEST"))):
-        from kinectdepthmapenhancement_amd import rccl_probe
+        import importlib.util       # the module file itself: the package import would pull torch into this parent
+        spec = importlib.util.spec_from_file_location("kde_rccl_probe", os.path.join(ROOT, "kinectdepthmapenhancement_amd", "rccl_probe.py"))
+        rccl_probe = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(rccl_probe)
         verdict = rccl_probe.run_probes(args.gpus, args.rccl_timeout, args.share_device)
         print(f"bench.py: RCCL probe x{args.gpus}: {'ok' if verdict['ok'] else 'FAILED -- ' + verdict['reason']} ({verdict['seconds']} s)",
               file=sys.stderr)
