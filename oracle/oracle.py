@@ -164,7 +164,10 @@ def parity_check(got, ref, env=None, rtol=1e-4, grid=None):
         ok = np.where(nan_got, nan_ok, np.where(got == 0, zero_ok, inside))
         bad_env = flagged & ~ok
         band, cond = int(((fl & Env.BAND) != 0).sum()), int(((fl & Env.COND) != 0).sum())
-    return {"bad": bad_nan | bad_zero | bad_rel | bad_env, "rel": rel, "census": deviation_census(got, ref, flagged, grid, rtol),
+    cen = deviation_census(got, ref, flagged, grid, rtol)
+    return {"bad": bad_nan | bad_zero | bad_rel | bad_env, "rel": rel, "census": cen,
+            **{k: cen[k] for k in ("n_rel_gt_rtol", "n_rel_gt_rtol_flagged", "n_zero_mask_differs", "n_nan_mask_differs")},
+            **{k: cen[k] for k in ("grid_pixels", "grid_rel_gt_rtol", "grid_zero_mask_differs") if k in cen},
             "n": int(ref.size), "flagged": int(flagged.sum()), "band": band, "cond": cond,
             "bad_nan": int(bad_nan.sum()), "bad_zero": int(bad_zero.sum()), "bad_rel": int(bad_rel.sum()),
             "outside_envelope": int(bad_env.sum()),
