@@ -418,6 +418,79 @@ struct AnalyzeSets {
     int band;
 };
 
+// The tail of analyzeClusters (.cu:425-566): the reference's 256-way tree over the threads' partial sums (levels +128, +64
+// through LDS, +32 ... +1 inside the first wavefront) and the new cluster record.  si / sf: 7 x 256 ints and 3 x 256 floats of LDS.
+__device__ __forceinline__ void analyze_reduce_and_store(const DaspGeom& g, int tid, int cluster_id, int (*si)[256], float (*sf)[256],
+                                                         int r_, int g_, int b_, int x_, int y_, int s_, int n_, float xf, float yf,
+                                                         float zf, kde_superpixel* __restrict__ mean, kde_float3* __restrict__ centers,
+                                                         const float* __restrict__ intr)
+{
+    si[0][tid] = r_; si[1][tid] = g_; si[2][tid] = b_; si[3][tid] = x_; si[4][tid] = y_;
+    si[5][tid] = s_; si[6][tid] = n_;
+    sf[0][tid] = xf; sf[1][tid] = yf; sf[2][tid] = zf;
+    __syncthreads();
+    // tree levels +128, +64 through LDS (.cu:425-454)
+    if (tid < 128) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) si[k][tid] += si[k][tid + 128];
+#pragma unroll
+        for (int k = 0; k < 3; k++) sf[k][tid] += sf[k][tid + 128];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        int iv[7];
+        float fv[3];
+#pragma unroll
+        for (int k = 0; k < 7; k++) iv[k] = si[k][tid] + si[k][tid + 64];
+#pragma unroll
+        for (int k = 0; k < 3; k++) fv[k] = sf[k][tid] + sf[k][tid + 64];
+        // levels +32 ... +1 inside the wavefront (.cu:455-528); lane 0 sees the clean tree
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) iv[k] += __shfl_down(iv[k], step, 64);
+#pragma unroll
+            for (int k = 0; k < 3; k++) fv[k] += __shfl_down(fv[k], step, 64);
+        }
+        if (tid == 0 && iv[5] != 0) {   // .cu:530-566
+            const int size = iv[5], np = iv[6];
+            int r = iv[0] / size > 255 ? 255 : iv[0] / size;
+            int gg = iv[1] / size > 255 ? 255 : iv[1] / size;
+            int b = iv[2] / size > 255 ? 255 : iv[2] / size;
+            r = r < 0 ? 0 : r;
+            gg = gg < 0 ? 0 : gg;
+            b = b < 0 ? 0 : b;
+            int pix_x, pix_y;
+            if (np != 0) {
+                kde_float3 c;
+                c.x = fv[0] / (float)np;
+                c.y = fv[1] / (float)np;
+                c.z = fv[2] / (float)np;
+                centers[cluster_id] = c;
+                const float nx = c.x / c.z, ny = c.y / c.z;
+                pix_x = f2i_rz(nx * intr[0] + intr[2]);
+                pix_y = f2i_rz(intr[5] - ny * intr[4]);
+                if (pix_x < 0 || pix_x >= g.width || pix_y < 0 || pix_y <= g.height) {   // sic, .cu:549
+                    pix_x = iv[3] / size;
+                    pix_y = iv[4] / size;
+                }
+            } else {
+                pix_x = iv[3] / size;
+                pix_y = iv[4] / size;
+            }
+            kde_superpixel m;
+            m.r = (uint8_t)r;
+            m.g = (uint8_t)gg;
+            m.b = (uint8_t)b;
+            m.pad_ = 0;
+            m.x = pix_x;
+            m.y = pix_y;
+            m.size = size;
+            mean[cluster_id] = m;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
                                                               const kde_float3* __restrict__ pts, AnalyzeSets sets,
                                                               const float* __restrict__ intr)
@@ -521,71 +594,195 @@ __global__ __launch_bounds__(256) void analyze_clusters_kernel(DaspGeom g, const
         }
       }
     }
-    si[0][tid] = r_; si[1][tid] = g_; si[2][tid] = b_; si[3][tid] = x_; si[4][tid] = y_;
-    si[5][tid] = s_; si[6][tid] = n_;
-    sf[0][tid] = xf; sf[1][tid] = yf; sf[2][tid] = zf;
-    __syncthreads();
-    // tree levels +128, +64 through LDS (.cu:425-454)
-    if (tid < 128) {
-#pragma unroll
-        for (int k = 0; k < 7; k++) si[k][tid] += si[k][tid + 128];
-#pragma unroll
-        for (int k = 0; k < 3; k++) sf[k][tid] += sf[k][tid + 128];
-    }
-    __syncthreads();
-    if (tid < 64) {
-        int iv[7];
-        float fv[3];
-#pragma unroll
-        for (int k = 0; k < 7; k++) iv[k] = si[k][tid] + si[k][tid + 64];
-#pragma unroll
-        for (int k = 0; k < 3; k++) fv[k] = sf[k][tid] + sf[k][tid + 64];
-        // levels +32 ... +1 inside the wavefront (.cu:455-528); lane 0 sees the clean tree
-#pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) {
-#pragma unroll
-            for (int k = 0; k < 7; k++) iv[k] += __shfl_down(iv[k], step, 64);
-#pragma unroll
-            for (int k = 0; k < 3; k++) fv[k] += __shfl_down(fv[k], step, 64);
-        }
-        if (tid == 0 && iv[5] != 0) {   // .cu:530-566
-            const int size = iv[5], np = iv[6];
-            int r = iv[0] / size > 255 ? 255 : iv[0] / size;
-            int gg = iv[1] / size > 255 ? 255 : iv[1] / size;
-            int b = iv[2] / size > 255 ? 255 : iv[2] / size;
-            r = r < 0 ? 0 : r;
-            gg = gg < 0 ? 0 : gg;
-            b = b < 0 ? 0 : b;
-            int pix_x, pix_y;
-            if (np != 0) {
-                kde_float3 c;
-                c.x = fv[0] / (float)np;
-                c.y = fv[1] / (float)np;
-                c.z = fv[2] / (float)np;
-                centers[cluster_id] = c;
-                const float nx = c.x / c.z, ny = c.y / c.z;
-                pix_x = f2i_rz(nx * intr[0] + intr[2]);
-                pix_y = f2i_rz(intr[5] - ny * intr[4]);
-                if (pix_x < 0 || pix_x >= g.width || pix_y < 0 || pix_y <= g.height) {   // sic, .cu:549
-                    pix_x = iv[3] / size;
-                    pix_y = iv[4] / size;
-                }
-            } else {
-                pix_x = iv[3] / size;
-                pix_y = iv[4] / size;
-            }
-            kde_superpixel m;
-            m.r = (uint8_t)r;
-            m.g = (uint8_t)gg;
-            m.b = (uint8_t)b;
-            m.pad_ = 0;
-            m.x = pix_x;
-            m.y = pix_y;
-            m.size = size;
-            mean[cluster_id] = m;
-        }
-    }
+    analyze_reduce_and_store(g, tid, cluster_id, si, sf, r_, g_, b_, x_, y_, s_, n_, xf, yf, zf, mean, centers, intr);
 }
+
+#ifdef KDE_AB_SWITCHES
+// ---- K8, row-coalesced form (r05) --------------------------------------------------------------------------------------
+// The kernel above is bound by the request queue of the L1 / texture-address path: a thread's sub-window is rpx pixels wide,
+// so at every step the 16 threads of a row touch pixels rpx apart -- 16 different cache lines per quarter-wave for the points
+// (12 B at a stride of 12 x rpx), once per MATCHED pixel and load.  But the 16 sub-windows of one thread row are one
+// contiguous run of 16 x rpx pixels of one image row, and only the float sums X, Y, Z depend on who adds what in which
+// order (per thread serially, then the 256-way tree); the integer sums r, g, b, x, y, size are associative.  So per
+// wavefront (4 thread rows) and sub-window row yy:
+//   loader phase -- the 64 lanes walk the 4 row segments in 4-pixel chunks, lane after lane (a chunk's 4 labels are one
+//     16-byte load, 64 consecutive chunks one contiguous kilobyte); a lane whose chunk holds a pixel of this cluster loads the
+//     chunk's 12 colour bytes and 48 point bytes (contiguous across lanes as well), adds the matched pixels to ITS integer
+//     sums, and leaves the 4 match flags and the 4 points in the wavefront's LDS stage;
+//   chain phase  -- every lane walks its own rpx pixels of the row in the reference's order and adds the staged points of the
+//     matched ones to its float sums (and counts z > 50).
+// The float chains are the reference's, add for add; the tree and the record are shared with the kernel above.
+// The stage is private to a wavefront (LDS operations of one wavefront execute in order: no workgroup barrier inside the loop).
+//
+// MEASURED AND NOT USED (measurement build only, KDE_K8_ROWS=1; tools/k8_rows_check.py, tools/bench_spdsr.py): labels, cluster
+// records and float centres are bit-identical to the kernel above in every configuration tried, but it is SLOWER -- per launch
+// in SPDSR at 1080p: 82 us in its first form (one chunk after the other: four dependent label -> point round trips per row),
+// 71 us with all loads of a row issued together and the labels one row ahead (130 VGPRs, 3 workgroups per CU by its 43 KB
+// stage), 88 us with the chain's LDS reads batched as well (197 VGPRs, 2 per CU) -- against 47.5 us.  The request-bound
+// kernel keeps 8 workgroups per CU and hundreds of independent gathers in flight; the staged form trades that for fewer,
+// wider requests and two dependent phases per row, and loses.  What would pay is reading each label once instead of 4.7
+// times (the windows of neighbouring clusters overlap by half), which needs several clusters per workgroup.
+__global__ __launch_bounds__(256) void analyze_clusters_rows_kernel(DaspGeom g, const uint8_t* __restrict__ bgr,
+                                                                   const kde_float3* __restrict__ pts, AnalyzeSets sets,
+                                                                   const float* __restrict__ intr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char k8_lds[];
+    const unsigned ncl = (unsigned)(g.rows * g.cols);
+    const unsigned gid = sets.band ? xcd_band_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned zz = gid / ncl, cid = gid - zz * ncl;
+    const unsigned frame = zz / (unsigned)sets.nsets, seg_i = zz - frame * (unsigned)sets.nsets;
+    const size_t fpx = (size_t)frame * g.width * g.height, fk = (size_t)frame * g.rows * g.cols;
+    bgr += fpx * 3;
+    pts += fpx;
+    const int32_t* __restrict__ labels = sets.s[seg_i].labels + fpx;
+    kde_superpixel* __restrict__ mean = sets.s[seg_i].mean + fk;
+    kde_float3* __restrict__ centers = sets.s[seg_i].centers + fk;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4, tyl = ty & 3, wave = tid >> 6, ln = tid & 63;
+    const int cluster_id = (int)cid;
+    const int rpx = g.wx * 2 / 16 + 1, rpy = g.wy * 2 / 16 + 1;
+    const int RW = 16 * rpx;                          // pixels of a row segment (all 16 sub-windows of a thread row)
+    const int CPS = RW / 4, NCH = 4 * CPS;            // 4-pixel chunks per segment / per wavefront step
+    const kde_superpixel m0 = mean[cluster_id];
+    // this wavefront's stage: 4 segments x RW match flags (bytes), then 4 x RW points (float3)
+    unsigned char* mt = k8_lds + (size_t)wave * ((size_t)4 * RW * 13);
+    float* pp = reinterpret_cast<float*>(mt + 4 * RW);
+    const int xs = (int)((unsigned)m0.x - (unsigned)(8 * rpx));          // 32-bit wrapping adds, as the reference's
+    const size_t last_pix = (size_t)g.width * g.height - 1;
+
+    int r_ = 0, g_ = 0, b_ = 0, x_ = 0, y_ = 0, s_ = 0, n_ = 0;
+    float xf = 0.0f, yf = 0.0f, zf = 0.0f;
+    // this lane's chunks (at most kMaxC: 16 rpx x 4 / 4 <= 256 chunks per step), fixed for the whole window: segment, first
+    // pixel, image column, which of the 4 columns lie inside the image, and the image row of sub-window row 0
+    constexpr int kMaxC = 4;
+    int c_off[kMaxC], c_ax[kMaxC], c_row0[kMaxC];
+    unsigned c_inx[kMaxC];                            // bit j: column ax + j is inside the image; bit 4: the chunk exists
+#pragma unroll
+    for (int k = 0; k < kMaxC; k++) {
+        const int c = ln + 64 * k;
+        const int sg = c / CPS, px0 = (c - sg * CPS) * 4;
+        c_off[k] = sg * RW + px0;
+        c_ax[k] = (int)((unsigned)xs + (unsigned)px0);
+        c_row0[k] = (int)((unsigned)m0.y + (unsigned)((4 * wave + sg - 8) * rpy));
+        c_inx[k] = c < NCH ? 16u : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (c_ax[k] + j >= 0 && c_ax[k] + j < g.width) c_inx[k] |= 1u << j;
+    }
+    // the labels of one sub-window row: issued for ALL chunks of the lane at once, and one row ahead of their use
+    auto load_labels = [&](int yy, int4 (&lab)[kMaxC]) {
+#pragma unroll
+        for (int k = 0; k < kMaxC; k++) {
+            lab[k] = make_int4(-2, -2, -2, -2);                          // never a cluster id
+            const int row = (int)((unsigned)c_row0[k] + (unsigned)yy);
+            if (!(c_inx[k] & 16u) || row < 0 || row >= g.height) continue;
+            const size_t q = (size_t)row * g.width + c_ax[k];
+            if ((c_inx[k] & 15u) == 15u) {
+                __builtin_memcpy(&lab[k], &labels[q], 16);
+            } else {
+                if (c_inx[k] & 1u) lab[k].x = labels[q];
+                if (c_inx[k] & 2u) lab[k].y = labels[q + 1];
+                if (c_inx[k] & 4u) lab[k].z = labels[q + 2];
+                if (c_inx[k] & 8u) lab[k].w = labels[q + 3];
+            }
+        }
+    };
+    int4 lab[kMaxC];
+    load_labels(0, lab);
+    for (int yy = 0; yy < rpy; yy++) {
+        // ---- loader phase: flags of every chunk, then the colour / point loads of ALL matched chunks before any is consumed ----
+        uint32_t flags[kMaxC], cb[kMaxC][3];
+        float pf[kMaxC][12];
+#pragma unroll
+        for (int k = 0; k < kMaxC; k++) {
+            flags[k] = (lab[k].x == cluster_id ? 1u : 0u) | (lab[k].y == cluster_id ? 1u << 8 : 0u) | (lab[k].z == cluster_id ? 1u << 16 : 0u) |
+                       (lab[k].w == cluster_id ? 1u << 24 : 0u);
+            if (c_inx[k] & 16u) *reinterpret_cast<uint32_t*>(mt + c_off[k]) = flags[k];
+            cb[k][0] = cb[k][1] = cb[k][2] = 0u;
+#pragma unroll
+            for (int i = 0; i < 12; i++) pf[k][i] = 0.0f;
+            if (!flags[k]) continue;
+            const int row = (int)((unsigned)c_row0[k] + (unsigned)yy);
+            const size_t q0 = (size_t)row * g.width + c_ax[k];
+            if ((c_inx[k] & 15u) == 15u) {
+                __builtin_memcpy(cb[k], bgr + q0 * 3, 12);                                   // 4 packed BGR pixels
+                __builtin_memcpy(pf[k], &pts[q0], 48);                                       // 4 points
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if ((flags[k] >> (8 * j)) & 1u) {
+                        const size_t q = q0 + j;
+                        const uint32_t v = (uint32_t)bgr[q * 3] | ((uint32_t)bgr[q * 3 + 1] << 8) | ((uint32_t)bgr[q * 3 + 2] << 16);
+                        // the same packed layout as the 12-byte load gives
+                        if (j == 0) cb[k][0] |= v;
+                        else if (j == 1) { cb[k][0] |= v << 24; cb[k][1] |= v >> 8; }
+                        else if (j == 2) { cb[k][1] |= v << 16; cb[k][2] |= v >> 16; }
+                        else cb[k][2] |= v << 8;
+                        const kde_float3 t = pts[q];
+                        pf[k][3 * j] = t.x; pf[k][3 * j + 1] = t.y; pf[k][3 * j + 2] = t.z;
+                    }
+            }
+        }
+        int4 nxt[kMaxC];
+        if (yy + 1 < rpy) load_labels(yy + 1, nxt);                   // in flight while this row is summed
+#pragma unroll
+        for (int k = 0; k < kMaxC; k++) {
+            if (!flags[k]) continue;
+            const int row = (int)((unsigned)c_row0[k] + (unsigned)yy);
+            const uint32_t px[4] = {cb[k][0] & 0xffffffu, (cb[k][0] >> 24) | ((cb[k][1] & 0xffffu) << 8),
+                                    (cb[k][1] >> 16) | ((cb[k][2] & 0xffu) << 16), cb[k][2] >> 8};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((flags[k] >> (8 * j)) & 1u) {
+                    r_ += (int)(px[j] & 0xffu);
+                    g_ += (int)((px[j] >> 8) & 0xffu);
+                    b_ += (int)((px[j] >> 16) & 0xffu);
+                    x_ += c_ax[k] + j;
+                    y_ += row;
+                    s_ += 1;
+                }
+            float4* dst = reinterpret_cast<float4*>(pp + (size_t)c_off[k] * 3);
+            dst[0] = make_float4(pf[k][0], pf[k][1], pf[k][2], pf[k][3]);
+            dst[1] = make_float4(pf[k][4], pf[k][5], pf[k][6], pf[k][7]);
+            dst[2] = make_float4(pf[k][8], pf[k][9], pf[k][10], pf[k][11]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the stage is written; the chains below read other lanes' chunks
+        __builtin_amdgcn_wave_barrier();
+        // ---- chain phase: this thread's rpx pixels of the row, in the reference's order ----
+        {
+            const int base = tyl * RW + tx * rpx;
+            for (int xx = 0; xx < rpx; xx++) {
+                if (mt[base + xx]) {
+                    const float* P = pp + (size_t)(base + xx) * 3;
+                    xf += P[0];
+                    yf += P[1];
+                    zf += P[2];
+                    n_ += P[2] > 50.0f ? 1 : 0;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the next row overwrites the stage
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < kMaxC; k++) lab[k] = nxt[k];
+    }
+    (void)last_pix;
+    __syncthreads();                                                  // every wavefront is done with its stage: reuse it for the tree
+    int (*si)[256] = reinterpret_cast<int (*)[256]>(k8_lds);
+    float (*sf)[256] = reinterpret_cast<float (*)[256]>(k8_lds + 7 * 256 * sizeof(int));
+    analyze_reduce_and_store(g, tid, cluster_id, si, sf, r_, g_, b_, x_, y_, s_, n_, xf, yf, zf, mean, centers, intr);
+}
+
+// LDS of the row-coalesced form: 4 wavefronts x 4 segments x 16 rpx pixels x (1 flag byte + 12 point bytes), at least the
+// 10 KB of the tree; 0 = the geometry does not fit (the request-bound kernel serves it)
+static size_t analyze_rows_lds(const DaspGeom& g)
+{
+    const int rpx = g.wx * 2 / 16 + 1;
+    const size_t need = (size_t)4 * 4 * 16 * rpx * 13;
+    const size_t tree = 7 * 256 * sizeof(int) + 3 * 256 * sizeof(float);
+    return need <= 48 * 1024 && rpx <= 16 ? (need > tree ? need : tree) : 0;     // (rpx <= 16: at most 4 chunks per lane and row)
+}
+#endif  // KDE_AB_SWITCHES (row-coalesced K8)
 
 }  // namespace
 
@@ -668,6 +865,15 @@ static int analyze_band_walk()
     return v;
 }
 
+#ifdef KDE_AB_SWITCHES
+// measurement build: KDE_K8_ROWS=1 selects the row-coalesced form of K8 where its stage fits (measured slower, see above)
+static bool analyze_rows_form()
+{
+    static const bool v = [] { const char* e = KDE_AB_ENV("KDE_K8_ROWS"); return e && e[0] != '0'; }();
+    return v;
+}
+#endif
+
 int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3* pts, const int32_t* labels,
                         kde_superpixel* mean, kde_float3* centers, const float* intr_dev, hipStream_t s)
 {
@@ -675,7 +881,12 @@ int launch_dasp_analyze(const DaspGeom& g, const uint8_t* bgr, const kde_float3*
     sets.s[0] = sets.s[1] = AnalyzeSet{labels, mean, centers};
     sets.nsets = 1;
     sets.band = analyze_band_walk();
-    hipLaunchKernelGGL(analyze_clusters_kernel, dim3(g.cols * g.rows), dim3(256), 0, s, g, bgr, pts, sets, intr_dev);
+#ifdef KDE_AB_SWITCHES
+    const size_t rows_lds = analyze_rows_form() ? analyze_rows_lds(g) : 0;
+    if (rows_lds) hipLaunchKernelGGL(analyze_clusters_rows_kernel, dim3(g.cols * g.rows), dim3(256), rows_lds, s, g, bgr, pts, sets, intr_dev);
+    else
+#endif
+        hipLaunchKernelGGL(analyze_clusters_kernel, dim3(g.cols * g.rows), dim3(256), 0, s, g, bgr, pts, sets, intr_dev);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }
@@ -690,7 +901,13 @@ int launch_dasp_analyze_dual(const DaspGeom& g, int n, const uint8_t* bgr, const
     sets.s[1] = AnalyzeSet{labels_b, mean_b, centers_b};
     sets.nsets = 2;
     sets.band = analyze_band_walk();
-    hipLaunchKernelGGL(analyze_clusters_kernel, dim3((unsigned)(g.cols * g.rows * 2 * n)), dim3(256), 0, s, g, bgr, pts, sets, intr_dev);
+    const dim3 grid((unsigned)(g.cols * g.rows * 2 * n));
+#ifdef KDE_AB_SWITCHES
+    const size_t rows_lds = analyze_rows_form() ? analyze_rows_lds(g) : 0;
+    if (rows_lds) hipLaunchKernelGGL(analyze_clusters_rows_kernel, grid, dim3(256), rows_lds, s, g, bgr, pts, sets, intr_dev);
+    else
+#endif
+        hipLaunchKernelGGL(analyze_clusters_kernel, grid, dim3(256), 0, s, g, bgr, pts, sets, intr_dev);
     KDE_HIP_TRY(hipGetLastError());
     return KDE_OK;
 }

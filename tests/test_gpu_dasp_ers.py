@@ -736,3 +736,30 @@ def test_spdsr_resident_cooperative_launches_from_three_host_threads(torch_cuda,
     want = _resident_child(tmp_path, cases, 0)
     got = _resident_child(tmp_path, cases, 1, threads=1)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_k8_row_coalesced_form_is_bit_identical(torch_cuda, F, oracle, synth, tmp_path):
+    """The measured-and-rejected row-coalesced form of analyzeClusters (analyze_clusters_rows_kernel; measurement build only,
+    KDE_K8_ROWS=1): coalesced 4-pixel chunks per wavefront row, integer sums by the loading lane, the float sums by the owning
+    thread from an LDS stage in the reference's order.  Labels, cluster records and float centres after 2 - 5 iterations must
+    equal the PRODUCT kernel's bit for bit (1080p, 640x480, a ragged frame, two other grids)."""
+    import os
+    import subprocess
+    import sys
+    import zlib
+    from conftest import ROOT
+    cases = ((1920, 1080, (15, 20), 5), (640, 480, (15, 20), 5), (203, 131, (5, 7), 3), (640, 480, (10, 8), 2), (320, 240, (6, 8), 4))
+    want = {}
+    for (w, h, g, it) in cases:
+        bgr, depth = synth.make_frame(33, w, h)
+        K = synth.intrinsics(w, h)
+        pts = oracle.p2r_depth(depth, K).view(np.float32).reshape(h, w, 3)
+        d = F.DepthAdaptiveSuperpixel(w, h)
+        d.SetParametor(g[0], g[1], K)
+        d.Segmentation(dev(torch_cuda, bgr), dev(torch_cuda, np.ascontiguousarray(pts)), 100.0, 20.0, 200.0, it)
+        want[f"{w}x{h}_{g}_{it}"] = tuple(zlib.crc32(host(t).tobytes()) for t in (d.getLabelDevice(), d.getMeanDataDevice(), d.getCentersDevice()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "k8_rows_check.py"), ROOT], env=dict(os.environ, KDE_K8_ROWS="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = eval(r.stdout.strip().splitlines()[-1])        # the tool prints one dict literal of CRC triples
+    assert got == want

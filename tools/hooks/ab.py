@@ -5,7 +5,7 @@ import os
 
 AB_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkde_hip_ab.so")
 SWITCHES = ("KDE_K0_2X2", "KDE_K0_BAND_WALK", "KDE_K8_NO_BAND_WALK", "KDE_K10_MASK_PRODUCT", "KDE_SWEEP_NO_BAND_WALK", "KDE_SPDSR_TWO_SWEEPS",
-            "KDE_SPDSR_RESIDENT")
+            "KDE_SPDSR_RESIDENT", "KDE_K8_ROWS")
 
 
 def use_ab_library() -> str:
